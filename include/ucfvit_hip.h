@@ -1,0 +1,193 @@
+/*
+ * ucfvit_hip.h — C ABI of libucfvit_hip.so: the MI355X (gfx950) kernels behind the UCF-VIT operator layer.
+ *
+ * The reference (irlyngaas/UCF-VIT) has no FFI: its drop-in boundary is the Python nn.Module operator layer
+ * (src/UCF_VIT/simple/building_blocks.py: PatchEmbed:30, Mlp:94, Attention:131, Block:194; MAE gathers in
+ * src/UCF_VIT/simple/arch.py:663,683).  Every entry point below replaces the torch/ATen call sites of one of
+ * those operators; the replaced reference lines are cited per function.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only, no torch types.  All pointers are DEVICE pointers unless stated otherwise.
+ *  - `dtype` selects the arithmetic/storage type of activations and (shadow) weights:
+ *       UCFVIT_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)  — the reference's `simple/` mode
+ *       UCFVIT_BF16 : bf16 storage, bf16 MFMA with fp32 accumulation          — the reference's fsdp MixedPrecision mode
+ *    statistics (LayerNorm mean/rstd, softmax log-sum-exp), losses, parameter gradients and optimizer state
+ *    are always fp32.
+ *  - `stream` is a hipStream_t passed as void*; every function only enqueues work on it (no synchronisation,
+ *    no allocation) so callers may capture the calls into a hipGraph.
+ *  - the caller owns every buffer (inputs, outputs, workspaces).  The library keeps no tensor memory.
+ *  - return value: 0 on success, <0 on error (see codes); ucfvit_last_error() returns a thread-local message.
+ *    Nothing throws across the ABI and nothing calls exit().
+ *  - re-entrant: may be called concurrently from the Python main thread and autograd worker threads.
+ */
+#ifndef UCFVIT_HIP_H
+#define UCFVIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCFVIT_ABI_VERSION 1
+
+#define UCFVIT_OK 0
+#define UCFVIT_ERR_INVALID_ARGUMENT (-1)
+#define UCFVIT_ERR_UNSUPPORTED (-2)
+#define UCFVIT_ERR_HIP (-3)
+
+#define UCFVIT_F32 0
+#define UCFVIT_BF16 1
+
+int ucfvit_abi_version(void);
+const char* ucfvit_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M,N] = epilogue( alpha * op(A)[M,K] · op(B)[K,N] )
+ *
+ * Replaces nn.Linear forward/backward on the hot path: qkv / proj (building_blocks.py:150,154,159,190),
+ * fc1 / fc2 (:115,119,123,127), the patch-embedding projection (conv k=s=p ≡ im2col + GEMM, :58-60,89),
+ * head (arch.py:268-271,484), MAE decoder_embed / decoder_pred (arch.py:552-559,685,700).
+ *
+ * Operand storage ("KC" = contraction index contiguous, "KS" = contraction index strided):
+ *   a_layout KC: A stored [M][K] row-major, lda = row stride      a_layout KS: A stored [K][M], lda = stride of k
+ *   b_layout KC: B stored [N][K] row-major (nn.Linear weight)     b_layout KS: B stored [K][N], ldb = stride of k
+ *   forward  y = x·Wᵀ      : (KC, KC)   A=x[M,K]   B=W[N,K]
+ *   dgrad    dx = dy·W     : (KC, KS)   A=dy[M,N'] B=W[N',K']   (contraction over W's rows)
+ *   wgrad    dW = dyᵀ·x    : (KS, KS)   A=dy[M',N] (as [K][M]), B=x[M',K'] (as [K][N])
+ *
+ * Epilogue, in order:  v = alpha*acc ; v += bias[n] ; act ; v += residual[m][n] ; v += C_old (accumulate) ; store.
+ *   act = UCFVIT_ACT_GELU      : if aux_out, aux_out[m][n] = v (pre-activation, saved for backward); v = gelu_erf(v)
+ *   act = UCFVIT_ACT_GELU_GRAD : v *= gelu_erf'(aux_in[m][n])   (dgrad through the activation; aux_in = saved pre-activation)
+ * `dtype` = type of A and B (and bias/residual/aux); `out_dtype` = type of C (UCFVIT_F32 for parameter gradients).
+ * ------------------------------------------------------------------------------------------------------ */
+#define UCFVIT_LAYOUT_KC 0
+#define UCFVIT_LAYOUT_KS 1
+#define UCFVIT_ACT_NONE 0
+#define UCFVIT_ACT_GELU 1
+#define UCFVIT_ACT_GELU_GRAD 2
+
+typedef struct ucfvit_gemm_desc {
+    const void* A;
+    const void* B;
+    void* C;
+    const void* bias;     /* [N] dtype, or NULL */
+    const void* residual; /* [M][ldr] dtype, or NULL */
+    const void* aux_in;   /* [M][ldaux] dtype, or NULL (ACT_GELU_GRAD) */
+    void* aux_out;        /* [M][ldaux] dtype, or NULL (ACT_GELU) */
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc, ldr, ldaux;
+    int32_t a_layout, b_layout;
+    int32_t dtype, out_dtype;
+    int32_t act;
+    int32_t accumulate; /* 1: C += result (gradient accumulation) */
+    float alpha;
+} ucfvit_gemm_desc;
+
+int ucfvit_gemm(const ucfvit_gemm_desc* desc, void* stream);
+
+/* column sums  out[n] (fp32) (+)= sum_m x[m][n]   — bias gradients of every nn.Linear (autograd of :159,190,123,127) */
+int64_t ucfvit_colsum_workspace(int64_t M, int64_t N); /* bytes of fp32 scratch for the deterministic two-stage sum */
+int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate, void* workspace, int dtype,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (biased variance, affine): nn.LayerNorm(D, eps) at building_blocks.py:212,226,
+ * arch.py:170,266 (eps 1e-6) and arch.py:560 (decoder_norm, eps 1e-5).
+ * x,y,dy,dx: [rows][D] dtype ; gamma,beta: [D] dtype ; mean,rstd: [rows] fp32 (saved for backward).
+ * bwd: dx = LN-grad(dy) + dres (dres: optional [rows][D] dtype, the residual branch's gradient, fused; NULL = none);
+ *      dgamma/dbeta are fp32 [D]; `accumulate` adds into them.  workspace: fp32, >= ucfvit_layernorm_bwd_workspace() bytes.
+ * ------------------------------------------------------------------------------------------------------ */
+int ucfvit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                         int64_t rows, int64_t D, float eps, int dtype, void* stream);
+int64_t ucfvit_layernorm_bwd_workspace(int64_t rows, int64_t D);
+int ucfvit_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, int accumulate,
+                         void* workspace, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention core, softmax(q·kᵀ·scale)·v, non-causal, no mask, dropout 0:
+ * building_blocks.py:159-189 (reshape [B,N,3,H,dh] → permute(2,0,3,1,4) → SDPA / explicit math → transpose → reshape).
+ * qkv : [B][N][3][H][dh] dtype — exactly the output of the qkv Linear (no permute copy is made)
+ * out : [B][N][H*dh] dtype     — already in the layout `proj` consumes
+ * lse : [B][H][N] fp32, log2-domain log-sum-exp of the scaled scores (saved for backward)
+ * bwd : dqkv has qkv's layout; delta_ws is fp32 [B][H][N] scratch.  dh ∈ {32, 64, 128}.
+ * ------------------------------------------------------------------------------------------------------ */
+int ucfvit_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh,
+                         float scale, int dtype, void* stream);
+int ucfvit_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                         float* delta_ws, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Patch embedding front end (PatchEmbed.forward, building_blocks.py:78-92): non-overlapping p×p(×p) patches of an
+ * NCHW / NCHWD fp32 image are laid out as GEMM rows [B·L][C·p^nd] with K-order (c, ph, pw[, pd]) = the flattening of
+ * the conv weight [D,C,p,p(,p)], token order row-major over the patch grid.  Coalesced reads of image rows through
+ * LDS tiles; output in `dtype`.  nd = 2 or 3; dims = {H, W} or {H, W, Dz}.
+ * ------------------------------------------------------------------------------------------------------ */
+int ucfvit_im2col(const float* img, void* cols, int64_t B, int64_t C, const int64_t* dims, int nd, int64_t p,
+                  int dtype, void* stream);
+
+/* Token assembly (VIT._pos_embed, arch.py:367-393): out[b][0] = cls + pos[0] (if cls), out[b][t+pre] = patches[b][t] + pos[t+pre].
+ * pos may be NULL (pos_embed='none').  bwd: dpatches = dout[:,pre:], dpos (fp32,[N][D]) (+)= sum_b dout, dcls (fp32,[D]) (+)= sum_b dout[:,0]. */
+int ucfvit_tokens_fwd(const void* patches, const void* cls, const void* pos, void* out, int64_t B, int64_t L, int64_t D,
+                      int has_cls, int dtype, void* stream);
+int ucfvit_tokens_bwd(const void* dout, void* dpatches, float* dpos, float* dcls, int64_t B, int64_t L, int64_t D,
+                      int has_cls, int accumulate, int dtype, void* stream);
+
+/* Softmax cross-entropy, mean over the batch (nn.CrossEntropyLoss, training_scripts/train_class_simple.py:24-30).
+ * logits [B][C] dtype, labels int64 [B]; loss: fp32 scalar (device); row_loss: fp32 [B] per-sample losses (also scratch);
+ * dlogits [B][C] dtype = grad_scale*(softmax - onehot)/B, or NULL. */
+int ucfvit_cross_entropy(const void* logits, const int64_t* labels, float* loss, float* row_loss, void* dlogits, int64_t B,
+                         int64_t C, float grad_scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * MAE random masking index math (MAE.random_masking, arch.py:663-681), bit-exact for distinct noise values:
+ * ids_restore[b][i] = rank of noise[b][i] in its row (= argsort(argsort(noise))), ids_shuffle[b][r] = argsort(noise)[r]
+ * (ids_keep = ids_shuffle[:, :len_keep]), mask[b][i] = (ids_restore[b][i] >= len_keep) ? 1 : 0.
+ * int64 indices [B][L], fp32 mask [B][L], like torch.
+ * ------------------------------------------------------------------------------------------------------ */
+int ucfvit_mae_mask(const float* noise, int64_t* ids_shuffle, int64_t* ids_restore, float* mask, int64_t B, int64_t L,
+                    int64_t len_keep, void* stream);
+
+/* Row gather  out[b][r][:] = src[b][idx[b*idx_stride + r]][:]  (torch.gather(seq, 1, ids_keep[...,None].repeat), arch.py:675) —
+ * bit-exact copy; src [B][L][D], out [B][R][D].  scatter is its adjoint for a duplicate-free idx:
+ * dsrc = 0; dsrc[b][idx[b][r]][:] = dout[b][r][:]. */
+int ucfvit_gather_rows(const void* src, const int64_t* idx, void* out, int64_t B, int64_t L, int64_t R, int64_t D,
+                       int64_t idx_stride, int dtype, void* stream);
+int ucfvit_scatter_rows(const void* dout, const int64_t* idx, void* dsrc, int64_t B, int64_t L, int64_t R, int64_t D,
+                        int64_t idx_stride, int dtype, void* stream);
+
+/* MAE un-shuffle (MAE.mask_head, arch.py:687-697): x_ = cat(x[B,R,D], mask_token repeated) ; out[b][i] = x_[b][ids_restore[b][i]] (+ pos[i]).
+ * bwd: dx[b][r] = dout[b][i : ids_restore==r] ; dmask_token (fp32 [D]) (+)= sum over masked positions ; dpos (fp32 [L][D]) (+)= sum_b dout. */
+int ucfvit_unshuffle_fwd(const void* x, const void* mask_token, const int64_t* ids_restore, const void* pos, void* out,
+                         int64_t B, int64_t L, int64_t R, int64_t D, int dtype, void* stream);
+int64_t ucfvit_unshuffle_bwd_workspace(int64_t B, int64_t D);
+int ucfvit_unshuffle_bwd(const void* dout, const int64_t* ids_restore, void* dx, float* dmask_token, float* dpos,
+                         int64_t B, int64_t L, int64_t R, int64_t D, int accumulate, void* workspace, int dtype, void* stream);
+
+/* MAE reconstruction loss against patchify(img) without materialising the target (utils/misc.py:14-33 'nchpwq->nhwpqc',
+ * training_scripts/train_masked_simple.py:43-47; masked variant utils/metrics.py:11-17).
+ * pred [B][L][p^nd*C] dtype with per-patch order (ph,pw[,pd],c); img NCHW(D) fp32; mask fp32 [B][L] or NULL (plain MSE over all).
+ * loss: fp32 scalar (device, overwritten); dpred = grad_scale * dloss/dpred (or NULL). workspace: >= 2049 floats. */
+int ucfvit_patch_mse(const void* pred, const float* img, const float* mask, float* loss, void* dpred, int64_t B, int64_t C,
+                     const int64_t* dims, int nd, int64_t p, float grad_scale, float* workspace, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter segment (torch.optim.AdamW semantics; utils/misc.py:58-84):
+ *   p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g² ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ * grads are fp32 (grad_dtype F32) or bf16 (BF16), multiplied by grad_scale first.  If shadow != NULL the updated
+ * parameter is also written as bf16 (the compute copy used by the bf16 kernels) in the same pass.
+ * ------------------------------------------------------------------------------------------------------ */
+int ucfvit_adamw(float* p, const void* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+                 int grad_dtype, void* stream);
+
+/* dtype conversion / scaling helpers (fp32 master → bf16 shadow cast; bf16 gradient transport for the DP all-reduce) */
+int ucfvit_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCFVIT_HIP_H */

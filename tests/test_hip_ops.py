@@ -1,0 +1,242 @@
+"""GPU parity tests of the HIP operators (through the C ABI) against the reference-generated golden vectors and the
+CPU oracle.  fp32 mode: tolerances of SURVEY.md §8a (1e-3 rel GEMM/attention ops, 1e-4 LayerNorm, bit-exact gathers);
+bf16 mode: same inputs, 2e-2 rel (bf16 has 8 mantissa bits; compared against the fp32 reference)."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
+
+
+def _mods():
+    from UCF_VIT.simple import building_blocks as BB
+    return BB
+
+
+def load_w(mod, g, prefix="w."):
+    mod.load_state_dict({k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)})
+    return mod.to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------- raw GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(394, 192, 64), (128, 128, 128), (130, 72, 200), (33, 40, 24), (788, 1024, 256), (5, 2, 64)])
+def test_gemm_layouts_and_epilogues(dtype, M, N, K):
+    from UCF_VIT._hip import ops
+    from UCF_VIT._hip.lib import ACT_GELU, ACT_GELU_GRAD, LAYOUT_KC, LAYOUT_KS
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) * 0.2
+    bias = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen)
+    Ad, Wd, bd, rd = (t.to(DEV, dtype) for t in (A, W, bias, res))
+    A64, W64, b64, r64 = (t.to(dtype).double() for t in (A, W, bias, res))   # reference sees the same rounded inputs
+    tol = TOL[dtype]
+    # forward: KC x KC, bias + residual
+    y = ops.linear_fwd(Ad, Wd, bd, residual=rd)
+    assert rel_err(y.float(), A64 @ W64.T + b64 + r64) < tol
+    # forward with GELU and saved pre-activation
+    h = torch.empty(M, N, dtype=dtype, device=DEV)
+    y = ops.linear_fwd(Ad, Wd, bd, act=ACT_GELU, aux_out=h)
+    pre = A64 @ W64.T + b64
+    assert rel_err(h.float(), pre) < tol
+    assert rel_err(y.float(), torch.nn.functional.gelu(pre)) < tol
+    # dgrad: KC x KS  (dy[M,N] @ W[N,K]), with gelu' fused
+    dy = torch.randn(M, N, generator=gen)
+    dyd, dy64 = dy.to(DEV, dtype), dy.to(dtype).double()
+    dx = ops.linear_dgrad(dyd, Wd)
+    assert rel_err(dx.float(), dy64 @ W64) < tol
+    if K % 4 == 0:
+        aux = torch.randn(M, K, generator=gen)
+        auxd, aux64 = aux.to(DEV, dtype), aux.to(dtype).double().requires_grad_(True)
+        torch.nn.functional.gelu(aux64).sum().backward()
+        dx = ops.linear_dgrad(dyd, Wd, act_grad_aux=auxd)
+        assert rel_err(dx.float(), (dy64 @ W64) * aux64.grad) < tol
+    # wgrad: KS x KS (dy^T @ A) -> fp32, then accumulate
+    dw = ops.linear_wgrad(dyd, Ad)
+    assert dw.dtype == torch.float32
+    assert rel_err(dw, dy64.T @ A64) < tol
+    ops.linear_wgrad(dyd, Ad, out=dw, accumulate=True)
+    assert rel_err(dw, 2 * (dy64.T @ A64)) < tol
+    # bias gradient
+    db = ops.colsum(dyd)
+    assert rel_err(db, dy64.sum(0)) < (1e-5 if dtype == torch.float32 else 1e-5)
+
+
+def test_gemm_f32_is_exact_fp32():
+    """fp32 MFMA path is an fmaf chain: agreement with an fp64 reference to ~1e-6 relative"""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(1)
+    A, W = torch.randn(256, 512, generator=gen), torch.randn(384, 512, generator=gen)
+    y = ops.linear_fwd(A.to(DEV), W.to(DEV))
+    assert rel_err(y, A.double() @ W.double().T) < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------- module-level operators
+def run_module(mod, g, dtype):
+    BB = _mods()
+    BB.set_compute_dtype(mod, dtype)
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = mod(x)
+    y.backward(g["gy"].to(DEV, y.dtype))
+    return x, y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name,make", [
+    ("op_mlp.npz", lambda BB: BB.Mlp(in_features=64, hidden_features=256)),
+    ("op_attn_none.npz", lambda BB: BB.Attention(64, num_heads=2, qkv_bias=True)),
+    ("op_attn_default.npz", lambda BB: BB.Attention(64, num_heads=2, qkv_bias=True)),
+    ("op_attn_n197_dh64.npz", lambda BB: BB.Attention(128, num_heads=2, qkv_bias=True)),
+    ("op_block.npz", lambda BB: BB.Block(64, 2, qkv_bias=True, norm_layer=partial(BB.LayerNorm, eps=1e-6))),
+    ("op_layernorm.npz", lambda BB: BB.LayerNorm(64, eps=1e-6)),
+])
+def test_operator_vs_reference(name, make, dtype):
+    g = load_golden(name)
+    mod = load_w(make(_mods()), g)
+    x, y = run_module(mod, g, dtype)
+    tol = TOL[dtype] if "layernorm" not in name or dtype == torch.bfloat16 else 1e-4
+    assert y.dtype == dtype
+    assert rel_err(y.float(), g["y"]) < tol
+    assert rel_err(x.grad.float(), g["gx"]) < tol
+    for k, p in mod.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32, k
+        assert rel_err(p.grad, g["g." + k]) < tol, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name,kw", [
+    ("op_patch2d.npz", dict(img_size=[32, 32], patch_size=8, in_chans=3, embed_dim=64, twoD=True)),
+    ("op_patch3d.npz", dict(img_size=[16, 16, 8], patch_size=4, in_chans=1, embed_dim=48, twoD=False)),
+])
+def test_patch_embed_vs_reference(name, kw, dtype):
+    BB = _mods()
+    g = load_golden(name)
+    mod = load_w(BB.PatchEmbed(**kw), g)
+    BB.set_compute_dtype(mod, dtype)
+    y = mod(g["x"].to(DEV))
+    y.backward(g["gy"].to(DEV, y.dtype))
+    tol = TOL[dtype]
+    assert rel_err(y.float(), g["y"]) < tol
+    for k, p in mod.named_parameters():
+        assert rel_err(p.grad, g["g." + k]) < tol, k
+
+
+def test_im2col_is_exact():
+    from UCF_VIT._hip import ops
+    x = torch.randn(2, 3, 32, 48)
+    cols = ops.im2col(x.to(DEV), 8, torch.float32).cpu()
+    ref = x.reshape(2, 3, 4, 8, 6, 8).permute(0, 2, 4, 1, 3, 5).reshape(2 * 24, 3 * 64)
+    assert torch.equal(cols, ref)
+    x3 = torch.randn(1, 2, 8, 8, 12)
+    cols = ops.im2col(x3.to(DEV), 4, torch.float32).cpu()
+    ref = x3.reshape(1, 2, 2, 4, 2, 4, 3, 4).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(12, 2 * 64)
+    assert torch.equal(cols, ref)
+
+
+# ---------------------------------------------------------------------------------------------- MAE index math (bit-exact)
+def test_mae_masking_bit_exact_vs_reference():
+    from UCF_VIT._hip import functional as HF
+    g = load_golden("mae_masking.npz")
+    kept, mask, ids = HF.RandomMaskFn.apply(g["seq"].to(DEV), g["noise"].to(DEV), 49)
+    assert ids.dtype == torch.int64 and torch.equal(ids.cpu(), g["ids_restore"])
+    assert torch.equal(mask.cpu(), g["mask"])
+    assert torch.equal(kept.cpu(), g["kept"])
+
+
+@pytest.mark.parametrize("B,L,D,ratio", [(3, 196, 1024, 0.75), (2, 64, 40, 0.5), (1, 1000, 8, 0.9), (2, 16, 64, 0.0)])
+def test_mae_masking_properties(B, L, D, ratio):
+    """size-independent properties: ids_restore is a permutation, mask has exactly L-len_keep ones, gather/scatter adjoint"""
+    from UCF_VIT._hip import functional as HF
+    gen = torch.Generator().manual_seed(L)
+    seq = torch.randn(B, L, D, generator=gen).to(DEV).requires_grad_(True)
+    noise = torch.rand(B, L, generator=gen).to(DEV)
+    len_keep = int(L * (1 - ratio))
+    kept, mask, ids = HF.RandomMaskFn.apply(seq, noise, len_keep)
+    assert torch.equal(torch.sort(ids, dim=1).values, torch.arange(L, device=DEV).expand(B, L))
+    assert torch.equal(mask.sum(1), torch.full((B,), float(L - len_keep), device=DEV))
+    ref_shuffle = torch.argsort(noise.cpu(), dim=1)
+    assert torch.equal(ids.cpu(), torch.argsort(ref_shuffle, dim=1))
+    assert torch.equal(kept.detach().cpu(), torch.gather(seq.detach().cpu(), 1, ref_shuffle[:, :len_keep, None].expand(-1, -1, D)))
+    gk = torch.randn_like(kept)
+    kept.backward(gk)
+    ref = torch.zeros(B, L, D)
+    ref.scatter_(1, ref_shuffle[:, :len_keep, None].expand(-1, -1, D), gk.cpu())
+    assert torch.equal(seq.grad.cpu(), ref)
+
+
+def test_mae_masking_ties_are_stable():
+    from UCF_VIT._hip import ops
+    noise = torch.tensor([[0.5, 0.1, 0.5, 0.1, 0.9, 0.5]], device=DEV)
+    shuffle, restore, mask = ops.mae_mask(noise, 3)
+    assert shuffle.cpu().tolist() == [[1, 3, 0, 2, 5, 4]]
+    assert restore.cpu().tolist() == [[2, 0, 3, 1, 5, 4]]
+    assert mask.cpu().tolist() == [[0.0, 0.0, 1.0, 0.0, 1.0, 1.0]]
+
+
+# ---------------------------------------------------------------------------------------------- losses / optimizer
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_entropy(dtype):
+    from UCF_VIT._hip import functional as HF
+    gen = torch.Generator().manual_seed(3)
+    logits = (torch.randn(37, 1000, generator=gen) * 3).to(dtype)
+    labels = torch.randint(0, 1000, (37,), generator=gen)
+    ref_in = logits.float().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss()(ref_in, labels)
+    ref.backward()
+    x = logits.to(DEV).requires_grad_(True)
+    loss = HF.cross_entropy(x, labels.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert rel_err(x.grad.float(), ref_in.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_patch_mse(masked):
+    from UCF_VIT._hip import functional as HF
+    from oracle import ucf_vit_ref as R
+    gen = torch.Generator().manual_seed(4)
+    img = torch.randn(3, 3, 32, 48, generator=gen)
+    pred = torch.randn(3, 24, 192, generator=gen)
+    mask = (torch.rand(3, 24, generator=gen) > 0.25).float() if masked else None
+    pr = pred.clone().requires_grad_(True)
+    tgt = R.patchify(img, 8)
+    ref = R.masked_mse(pr, tgt, mask) if masked else torch.nn.MSELoss()(pr, tgt)
+    ref.backward()
+    pd = pred.to(DEV).requires_grad_(True)
+    loss = HF.patch_mse(pd, img.to(DEV), 8, mask.to(DEV) if masked else None)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert rel_err(pd.grad, pr.grad) < 1e-5
+
+
+def test_adamw_matches_torch():
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(5)
+    n = 1003
+    p0, g = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2)
+    pd = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 4):
+        pr.grad = g * step
+        opt.step()
+        ops.adamw(pd, (g * step).to(DEV), m, v, sh, 1e-3, 0.9, 0.95, 1e-8, 1e-2, step)
+    assert rel_err(pd, pr.detach()) < 1e-6
+    assert torch.equal(sh.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    BB = _mods()
+    mod = BB.Mlp(in_features=64, hidden_features=256)
+    with pytest.raises(RuntimeError):
+        mod(torch.randn(2, 4, 64))

@@ -1,0 +1,382 @@
+"""torch.autograd.Function wrappers that drive the HIP kernels for the UCF-VIT operator layer.
+
+Each Function's forward/backward is a fixed sequence of libucfvit_hip.so launches (no torch math on the hot path).
+Reference semantics: src/UCF_VIT/simple/building_blocks.py (PatchEmbed:78-92, Mlp:122-129, Attention:157-192,
+Block:236-239) and src/UCF_VIT/simple/arch.py (_pos_embed:367-393, random_masking:663-681, mask_head:683-702).
+
+Parameter gradients are written by the kernels straight into the flat fp32 gradient buffer of the model's
+HipParamStore when there is one (see params.py); the view is handed to autograd so hooks (e.g. a DDP reducer) still fire.
+"""
+import torch
+
+from . import ops
+from .lib import ACT_GELU, ACT_NONE
+from .params import compute_param, grad_target
+
+
+def _as(x, dtype):
+    """x in the compute dtype, contiguous (kernel-side cast, no torch math)."""
+    if x.dtype == dtype:
+        return x if x.is_contiguous() else x.contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    return ops.cast(x, torch.empty(x.shape, dtype=dtype, device=x.device))
+
+
+def _ret_grad(g, like):
+    """gradient handed back to autograd must carry the dtype of the forward input"""
+    if g is None or g.dtype == like:
+        return g
+    return ops.cast(g, torch.empty(g.shape, dtype=like, device=g.device))
+
+
+# ---------------------------------------------------------------------------------------------- param-grad helpers
+def _wgrad(weight, dy2, x2):
+    out, acc = grad_target(weight)
+    o2 = out.view(out.shape[0], -1) if out is not None else None
+    r = ops.linear_wgrad(dy2, x2, out=o2, accumulate=acc)
+    if acc:
+        return None
+    return out if out is not None else r.view(weight.shape)
+
+
+def _bgrad(bias, dy2):
+    out, acc = grad_target(bias)
+    r = ops.colsum(dy2, out=out, accumulate=acc)
+    return None if acc else r
+
+
+def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None):
+    ow, aw = grad_target(weight)
+    ob, ab = grad_target(bias)
+    if aw != ab or (ow is None) != (ob is None):  # mixed states: take the simple route
+        ow = ob = None
+        aw = ab = False
+    dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma_c, mean, rstd, dres=dres, dgamma=ow, dbeta=ob, accumulate=aw)
+    return dx, (None if aw else dg), (None if ab else db)
+
+
+# ---------------------------------------------------------------------------------------------- raw fused sequences
+def _attn_fwd(x2, B, N, H, wqkv, bqkv, wproj, bproj, residual):
+    D = x2.shape[1]
+    dh = D // H
+    qkv = ops.linear_fwd(x2, wqkv, bqkv)                               # K4: qkv GEMM + bias
+    o, lse = ops.attention_fwd(qkv, B, N, H, dh, dh ** -0.5)           # K5: fused softmax(QKᵀ)V
+    y = ops.linear_fwd(o, wproj, bproj, residual=residual)             # K6: proj GEMM + bias (+ residual)
+    return y, (qkv, o, lse)
+
+
+def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs):
+    qkv, o, lse = saved
+    D = x2.shape[1]
+    dh = D // H
+    g_projw = _wgrad(p_projw, dy2, o) if needs[2] else None
+    g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
+    do = ops.linear_dgrad(dy2, wproj)
+    dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
+    g_qkvw = _wgrad(p_qkvw, dqkv, x2) if needs[0] else None
+    g_qkvb = _bgrad(p_qkvb, dqkv) if (p_qkvb is not None and needs[1]) else None
+    dx = ops.linear_dgrad(dqkv, wqkv)
+    return dx, (g_qkvw, g_qkvb, g_projw, g_projb)
+
+
+def _mlp_fwd(x2, w1, b1, w2, b2, residual):
+    h = torch.empty((x2.shape[0], w1.shape[0]), dtype=x2.dtype, device=x2.device)
+    a = ops.linear_fwd(x2, w1, b1, act=ACT_GELU, aux_out=h)            # K7: fc1 GEMM + bias + erf-GELU (pre-activation kept)
+    y = ops.linear_fwd(a, w2, b2, residual=residual)                   # K7: fc2 GEMM + bias (+ residual)
+    return y, (h, a)
+
+
+def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs):
+    h, a = saved
+    g_w2 = _wgrad(p_w2, dy2, a) if needs[2] else None
+    g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
+    dh = ops.linear_dgrad(dy2, w2, act_grad_aux=h)                     # dgrad fused with gelu'(h)
+    g_w1 = _wgrad(p_w1, dh, x2) if needs[0] else None
+    g_b1 = _bgrad(p_b1, dh) if (p_b1 is not None and needs[1]) else None
+    dx = ops.linear_dgrad(dh, w1)
+    return dx, (g_w1, g_b1, g_w2, g_b2)
+
+
+# ---------------------------------------------------------------------------------------------- Functions
+class LinearFn(torch.autograd.Function):
+    """y = x·Wᵀ + b over the last dim (nn.Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdtype):
+        xin = _as(x, cdtype)
+        x2 = xin.reshape(-1, xin.shape[-1])
+        w, b = compute_param(weight, cdtype), compute_param(bias, cdtype)
+        y = ops.linear_fwd(x2, w, b)
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.cdtype, ctx.in_dtype, ctx.in_shape = cdtype, x.dtype, x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        dy2 = _as(dy, ctx.cdtype).reshape(-1, dy.shape[-1])
+        w = compute_param(weight, ctx.cdtype)
+        gw = _wgrad(weight, dy2, x2) if ctx.needs_input_grad[1] else None
+        gb = _bgrad(bias, dy2) if (bias is not None and ctx.needs_input_grad[2]) else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _ret_grad(ops.linear_dgrad(dy2, w).view(ctx.in_shape), ctx.in_dtype)
+        return dx, gw, gb, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, cdtype):
+        xin = _as(x, cdtype)
+        x2 = xin.reshape(-1, xin.shape[-1])
+        g, b = compute_param(weight, cdtype), compute_param(bias, cdtype)
+        y, mean, rstd = ops.layernorm_fwd(x2, g, b, eps)
+        ctx.save_for_backward(x2, mean, rstd, weight, bias)
+        ctx.cdtype, ctx.in_dtype, ctx.in_shape = cdtype, x.dtype, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, weight, bias = ctx.saved_tensors
+        dy2 = _as(dy, ctx.cdtype).reshape(x2.shape)
+        dx, dg, db = _ln_bwd(dy2, x2, compute_param(weight, ctx.cdtype), mean, rstd, weight, bias)
+        return _ret_grad(dx.view(ctx.in_shape), ctx.in_dtype), dg, db, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """Attention.forward (building_blocks.py:157-192): qkv Linear -> fused SDPA -> proj Linear."""
+
+    @staticmethod
+    def forward(ctx, x, qkvw, qkvb, projw, projb, num_heads, cdtype):
+        xin = _as(x, cdtype)
+        B, N, D = xin.shape
+        x2 = xin.view(B * N, D)
+        c = lambda p: compute_param(p, cdtype)
+        y, saved = _attn_fwd(x2, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), None)
+        ctx.save_for_backward(x2, *saved, qkvw, qkvb, projw, projb)
+        ctx.meta = (B, N, num_heads, cdtype, x.dtype)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, qkv, o, lse, qkvw, qkvb, projw, projb = ctx.saved_tensors
+        B, N, H, cdtype, in_dtype = ctx.meta
+        dy2 = _as(dy, cdtype).reshape(x2.shape)
+        c = lambda p: compute_param(p, cdtype)
+        dx, g = _attn_bwd(dy2, x2, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, ctx.needs_input_grad[1:5])
+        return (_ret_grad(dx.view(B, N, -1), in_dtype),) + g + (None, None)
+
+
+class MlpFn(torch.autograd.Function):
+    """Mlp.forward (building_blocks.py:122-129): fc1 -> erf-GELU -> fc2 (drops are p=0, norm=Identity)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, cdtype):
+        xin = _as(x, cdtype)
+        x2 = xin.reshape(-1, xin.shape[-1])
+        c = lambda p: compute_param(p, cdtype)
+        y, saved = _mlp_fwd(x2, c(w1), c(b1), c(w2), c(b2), None)
+        ctx.save_for_backward(x2, *saved, w1, b1, w2, b2)
+        ctx.meta = (cdtype, x.dtype, x.shape)
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, a, w1, b1, w2, b2 = ctx.saved_tensors
+        cdtype, in_dtype, in_shape = ctx.meta
+        dy2 = _as(dy, cdtype).reshape(-1, dy.shape[-1])
+        c = lambda p: compute_param(p, cdtype)
+        dx, g = _mlp_bwd(dy2, x2, (h, a), c(w1), c(w2), w1, b1, w2, b2, ctx.needs_input_grad[1:5])
+        return (_ret_grad(dx.view(in_shape), in_dtype),) + g + (None,)
+
+
+class BlockFn(torch.autograd.Function):
+    """Block.forward (building_blocks.py:236-239) with LayerScale/DropPath = Identity:
+    x1 = x + proj(attn(norm1(x))) ; y = x1 + fc2(gelu(fc1(norm2(x1)))).  7 forward launches, residual adds and the
+    activation fused into GEMM epilogues; the residual-branch gradients are fused into the LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b, num_heads, eps, cdtype):
+        xin = _as(x, cdtype)
+        B, N, D = xin.shape
+        x2 = xin.view(B * N, D)
+        c = lambda p: compute_param(p, cdtype)
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x2, c(n1w), c(n1b), eps)
+        x1, sa = _attn_fwd(ln1, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), x2)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, c(n2w), c(n2b), eps)
+        y, sm = _mlp_fwd(ln2, c(f1w), c(f1b), c(f2w), c(f2b), x1)
+        ctx.save_for_backward(x2, mean1, rstd1, ln1, *sa, x1, mean2, rstd2, ln2, *sm,
+                              n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.meta = (B, N, num_heads, cdtype, x.dtype)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, h, a,
+         n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b) = ctx.saved_tensors
+        B, N, H, cdtype, in_dtype = ctx.meta
+        need = ctx.needs_input_grad
+        c = lambda p: compute_param(p, cdtype)
+        dy2 = _as(dy, cdtype).reshape(x2.shape)
+        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13])
+        dx1, g_n2w, g_n2b = _ln_bwd(dln2, x1, c(n2w), mean2, rstd2, n2w, n2b, dres=dy2)        # + residual branch
+        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7])
+        dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1)
+        return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed.forward (building_blocks.py:78-92): conv(k=s=p) == im2col + GEMM + bias -> [B, L, D]."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, patch, cdtype):
+        if img.dtype != torch.float32:
+            img = img.float()
+        img = img if img.is_contiguous() else img.contiguous()
+        cols = ops.im2col(img, patch, cdtype)
+        w = compute_param(weight, cdtype)
+        y = ops.linear_fwd(cols, w.view(w.shape[0], -1), compute_param(bias, cdtype))
+        ctx.save_for_backward(cols, weight, bias)
+        ctx.cdtype = cdtype
+        B = img.shape[0]
+        return y.view(B, -1, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight, bias = ctx.saved_tensors
+        dy2 = _as(dy, ctx.cdtype).reshape(cols.shape[0], -1)
+        gw = _wgrad(weight, dy2, cols) if ctx.needs_input_grad[1] else None
+        gb = _bgrad(bias, dy2) if (bias is not None and ctx.needs_input_grad[2]) else None
+        return None, gw, gb, None, None   # no gradient w.r.t. the image (leaf input of the training step)
+
+
+class TokensFn(torch.autograd.Function):
+    """VIT._pos_embed (arch.py:367-393): cat(cls, x) + pos_embed."""
+
+    @staticmethod
+    def forward(ctx, x, cls, pos, cdtype):
+        xin = _as(x, cdtype)
+        B, Lp, D = xin.shape
+        out = ops.tokens_fwd(xin.view(B * Lp, D), compute_param(cls, cdtype), compute_param(pos, cdtype), B, Lp, D)
+        ctx.save_for_backward(cls, pos)
+        ctx.meta = (B, Lp, D, cdtype, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cls, pos = ctx.saved_tensors
+        B, Lp, D, cdtype, in_dtype = ctx.meta
+        d = _as(dout, cdtype)
+        want_pos = pos is not None and ctx.needs_input_grad[2]
+        has_cls = cls is not None
+        op = oc = None
+        ap = ac = False
+        if want_pos:
+            op, ap = grad_target(pos)
+        if has_cls:
+            oc, ac = grad_target(cls)
+        if (want_pos and has_cls and ap != ac) or (want_pos and has_cls and ((op is None) != (oc is None))):
+            op = oc = None
+            ap = ac = False
+        acc = ap or ac
+        dpatches, dpos, dcls = ops.tokens_bwd(d, B, Lp, D, has_cls, want_pos,
+                                              dpos=op.view(-1, D) if op is not None else None,
+                                              dcls=oc.view(-1) if oc is not None else None, accumulate=acc,
+                                              want_patches=ctx.needs_input_grad[0])
+        g_pos = None if (not want_pos or acc) else (op if op is not None else dpos.view(pos.shape))
+        g_cls = None if (not has_cls or acc) else (oc if oc is not None else dcls.view(cls.shape))
+        gx = _ret_grad(dpatches.view(B, Lp, D), in_dtype) if dpatches is not None else None
+        return gx, g_cls, g_pos, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(logits, labels), mean reduction (train_class_simple.py:24-30); fp32 loss scalar."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        l2 = logits if logits.is_contiguous() else logits.contiguous()
+        loss, dl, _ = ops.cross_entropy(l2, labels, 1.0, want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g.to(dl.dtype), None
+
+
+class RandomMaskFn(torch.autograd.Function):
+    """MAE.random_masking (arch.py:663-681) for a given noise tensor: returns (kept tokens, mask, ids_restore)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, len_keep):
+        B, Lp, D = x.shape
+        xin = x if x.is_contiguous() else x.contiguous()
+        ids_shuffle, ids_restore, mask = ops.mae_mask(noise.contiguous().float(), len_keep)
+        kept = ops.gather_rows(xin, ids_shuffle, len_keep, Lp)
+        ctx.save_for_backward(ids_shuffle)
+        ctx.meta = (Lp, len_keep)
+        ctx.mark_non_differentiable(mask, ids_restore)
+        return kept, mask, ids_restore
+
+    @staticmethod
+    def backward(ctx, dkept, _dm, _di):
+        (ids_shuffle,) = ctx.saved_tensors
+        Lp, len_keep = ctx.meta
+        d = dkept if dkept.is_contiguous() else dkept.contiguous()
+        return ops.scatter_rows(d, ids_shuffle, Lp, Lp), None, None
+
+
+class UnshuffleFn(torch.autograd.Function):
+    """MAE.mask_head's un-shuffle (arch.py:687-697): gather(cat(x, mask_tokens), ids_restore) + decoder_pos_embed."""
+
+    @staticmethod
+    def forward(ctx, x, mask_token, ids_restore, pos, cdtype):
+        xin = _as(x, cdtype)
+        out = ops.unshuffle_fwd(xin, compute_param(mask_token, cdtype).reshape(-1), ids_restore, compute_param(pos, cdtype))
+        ctx.save_for_backward(ids_restore, mask_token, pos)
+        ctx.meta = (xin.shape[1], cdtype, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids_restore, mask_token, pos = ctx.saved_tensors
+        R, cdtype, in_dtype = ctx.meta
+        d = _as(dout, cdtype)
+        want_pos = pos is not None and ctx.needs_input_grad[3]
+        om, am = grad_target(mask_token)
+        op, ap = grad_target(pos) if want_pos else (None, False)
+        if want_pos and (am != ap or ((om is None) != (op is None))):
+            om = op = None
+            am = ap = False
+        dx, dmask, dpos = ops.unshuffle_bwd(d, ids_restore, R, want_pos, dmask=om.view(-1) if om is not None else None,
+                                            dpos=op.view(-1, d.shape[-1]) if op is not None else None, accumulate=am)
+        g_m = None if am else (om if om is not None else dmask.view(mask_token.shape))
+        g_p = None if (not want_pos or ap) else (op if op is not None else dpos.view(pos.shape))
+        return _ret_grad(dx, in_dtype), g_m, None, g_p, None
+
+
+class PatchMSEFn(torch.autograd.Function):
+    """MSE between pred and patchify(img) (misc.py:14-33 + train_masked_simple.py:43-47), optional mask (metrics.py:11-17)."""
+
+    @staticmethod
+    def forward(ctx, pred, img, mask, patch):
+        p = pred if pred.is_contiguous() else pred.contiguous()
+        im = img if img.is_contiguous() else img.contiguous()
+        loss, dpred = ops.patch_mse(p, im.float(), patch, mask=mask, grad_scale=1.0, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g.to(dpred.dtype), None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- public helpers
+def cross_entropy(logits, labels):
+    return CrossEntropyFn.apply(logits, labels)
+
+
+def patch_mse(pred, img, patch_size, mask=None):
+    return PatchMSEFn.apply(pred, img, mask, patch_size)

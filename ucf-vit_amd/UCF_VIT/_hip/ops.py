@@ -1,0 +1,315 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).  Every function enqueues HIP kernels on torch's
+current stream and returns torch tensors that own the outputs.  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib as _l
+from .lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, BF16, F32, LAYOUT_KC, LAYOUT_KS
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"UCF_VIT HIP ops support float32 and bfloat16 tensors, got {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda) device, got {t.device}. "
+                           "UCF_VIT operators run only through libucfvit_hip.so; there is no CPU path.")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """fp32 scratch, cached per (device, stream): used and consumed inside one ABI call sequence on that stream."""
+    key = (device.index, _stream())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(int(nbytes) // 4 + 1, 1 << 16), dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None, residual=None, act=ACT_NONE,
+         aux_in=None, aux_out=None, accumulate=False, alpha=1.0):
+    """C[M,N] = epilogue(alpha * op(A)·op(B)); A, B are 2-D row-major tensors (see include/ucfvit_hip.h)."""
+    L = _l.load()
+    _chk(A, "gemm.A"), _chk(B, "gemm.B")
+    if A.dtype != B.dtype:
+        raise TypeError("gemm: A and B must have the same dtype")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    d = _l.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    d.bias, d.residual, d.aux_in, d.aux_out = _p(bias), _p(residual), _p(aux_in), _p(aux_out)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    aux = aux_in if aux_in is not None else aux_out
+    d.ldaux = aux.stride(0) if aux is not None else 0
+    d.a_layout, d.b_layout = a_layout, b_layout
+    d.dtype, d.out_dtype = dt(A), dt(out)
+    d.act, d.accumulate, d.alpha = act, 1 if accumulate else 0, alpha
+    _l.check(L.ucfvit_gemm(ctypes.byref(d), _stream()), "ucfvit_gemm")
+    return out
+
+
+def linear_fwd(x2, w, b=None, act=ACT_NONE, residual=None, aux_out=None, out=None):
+    """y[M,N] = act(x2[M,K]·w[N,K]ᵀ + b) + residual   (nn.Linear forward, building_blocks.py:123,127,159,190)"""
+    M, K = x2.shape
+    N = w.shape[0]
+    return gemm(x2, w, M, N, K, LAYOUT_KC, LAYOUT_KS if False else LAYOUT_KC, out=out, bias=b, residual=residual, act=act,
+                aux_out=aux_out)
+
+
+def linear_dgrad(dy2, w, act_grad_aux=None, out=None):
+    """dx[M,K] = dy2[M,N]·w[N,K]  (optionally times gelu'(aux) for the fc1 pre-activation)"""
+    M, N = dy2.shape
+    K = w.shape[1]
+    return gemm(dy2, w, M, K, N, LAYOUT_KC, LAYOUT_KS, out=out, act=ACT_GELU_GRAD if act_grad_aux is not None else ACT_NONE,
+                aux_in=act_grad_aux)
+
+
+def linear_wgrad(dy2, x2, out=None, accumulate=False):
+    """dW[N,K] (fp32) = dy2[M,N]ᵀ·x2[M,K]"""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    return gemm(dy2, x2, N, K, M, LAYOUT_KS, LAYOUT_KS, out=out, out_dtype=torch.float32, accumulate=accumulate)
+
+
+def colsum(x2, out=None, accumulate=False):
+    L = _l.load()
+    _chk(x2, "colsum.x")
+    M, N = x2.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x2.device)
+    ws = workspace(L.ucfvit_colsum_workspace(M, N), x2.device)
+    _l.check(L.ucfvit_colsum(x2.data_ptr(), out.data_ptr(), M, N, x2.stride(0), 1 if accumulate else 0, ws.data_ptr(), dt(x2),
+                             _stream()), "ucfvit_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x2, gamma, beta, eps):
+    L = _l.load()
+    _chk(x2, "layernorm.x")
+    rows, D = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    _l.check(L.ucfvit_layernorm_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                    rows, D, eps, dt(x2), _stream()), "ucfvit_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False):
+    L = _l.load()
+    _chk(dy2, "layernorm_bwd.dy")
+    rows, D = x2.shape
+    dx = torch.empty_like(x2)
+    if dgamma is None:
+        dgamma = torch.empty(D, dtype=torch.float32, device=x2.device)
+    if dbeta is None:
+        dbeta = torch.empty(D, dtype=torch.float32, device=x2.device)
+    ws = workspace(L.ucfvit_layernorm_bwd_workspace(rows, D), x2.device)
+    _l.check(L.ucfvit_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
+                                    dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, 1 if accumulate else 0,
+                                    ws.data_ptr(), dt(x2), _stream()), "ucfvit_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv, B, N, H, dh, scale):
+    """qkv: [B*N, 3*H*dh] (the qkv Linear's output) -> out [B*N, H*dh], lse [B,H,N]"""
+    L = _l.load()
+    _chk(qkv, "attention.qkv")
+    out = torch.empty((B * N, H * dh), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _l.check(L.ucfvit_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, dh, scale, dt(qkv), _stream()),
+             "ucfvit_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, N, H, dh, scale):
+    L = _l.load()
+    _chk(dout, "attention_bwd.dout")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _l.check(L.ucfvit_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                                    B, N, H, dh, scale, dt(qkv), _stream()), "ucfvit_attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ front end
+def im2col(img, p, out_dtype):
+    """img fp32 [B,C,H,W] or [B,C,H,W,Z] -> [B*L, C*p^nd] in out_dtype, K-order (c, ph, pw[, pd])"""
+    L = _l.load()
+    _chk(img, "im2col.img")
+    if img.dtype != torch.float32:
+        raise TypeError("im2col: image must be float32 (as the reference dataloaders deliver it)")
+    B, C = img.shape[0], img.shape[1]
+    sp = list(img.shape[2:])
+    nd = len(sp)
+    Lp = 1
+    for s in sp:
+        Lp *= s // p
+    cols = torch.empty((B * Lp, C * p ** nd), dtype=out_dtype, device=img.device)
+    dims = (ctypes.c_int64 * 3)(*(sp + [1] * (3 - nd)))
+    _l.check(L.ucfvit_im2col(img.data_ptr(), cols.data_ptr(), B, C, dims, nd, p, _DT[out_dtype], _stream()), "ucfvit_im2col")
+    return cols
+
+
+def tokens_fwd(patches, cls, pos, B, Lp, D):
+    L = _l.load()
+    _chk(patches, "tokens.patches")
+    pre = 0 if cls is None else 1
+    out = torch.empty((B, Lp + pre, D), dtype=patches.dtype, device=patches.device)
+    _l.check(L.ucfvit_tokens_fwd(patches.data_ptr(), _p(cls), _p(pos), out.data_ptr(), B, Lp, D, pre, dt(patches), _stream()),
+             "ucfvit_tokens_fwd")
+    return out
+
+
+def tokens_bwd(dout, B, Lp, D, has_cls, want_pos, dpos=None, dcls=None, accumulate=False, want_patches=True):
+    L = _l.load()
+    _chk(dout, "tokens_bwd.dout")
+    dev = dout.device
+    dpatches = torch.empty((B * Lp, D), dtype=dout.dtype, device=dev) if want_patches else None
+    pre = 1 if has_cls else 0
+    if want_pos and dpos is None:
+        dpos = torch.empty((Lp + pre, D), dtype=torch.float32, device=dev)
+    if has_cls and dcls is None:
+        dcls = torch.empty(D, dtype=torch.float32, device=dev)
+    _l.check(L.ucfvit_tokens_bwd(dout.data_ptr(), _p(dpatches), _p(dpos) if want_pos else None, _p(dcls) if has_cls else None, B, Lp, D,
+                                 pre, 1 if accumulate else 0, dt(dout), _stream()), "ucfvit_tokens_bwd")
+    return dpatches, dpos, dcls
+
+
+def cross_entropy(logits, labels, grad_scale=1.0, want_grad=True):
+    """returns (loss fp32 scalar tensor, dlogits or None, row_loss)"""
+    L = _l.load()
+    _chk(logits, "cross_entropy.logits"), _chk(labels, "cross_entropy.labels")
+    if labels.dtype != torch.int64:
+        raise TypeError("cross_entropy: labels must be int64")
+    B, C = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    _l.check(L.ucfvit_cross_entropy(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), rows.data_ptr(), _p(dl), B, C, grad_scale,
+                                    dt(logits), _stream()), "ucfvit_cross_entropy")
+    return loss, dl, rows
+
+
+# ------------------------------------------------------------------------------------------------ MAE
+def mae_mask(noise, len_keep):
+    L = _l.load()
+    _chk(noise, "mae_mask.noise")
+    if noise.dtype != torch.float32:
+        raise TypeError("mae_mask: noise must be float32")
+    B, Lp = noise.shape
+    ids_shuffle = torch.empty((B, Lp), dtype=torch.int64, device=noise.device)
+    ids_restore = torch.empty((B, Lp), dtype=torch.int64, device=noise.device)
+    mask = torch.empty((B, Lp), dtype=torch.float32, device=noise.device)
+    _l.check(L.ucfvit_mae_mask(noise.data_ptr(), ids_shuffle.data_ptr(), ids_restore.data_ptr(), mask.data_ptr(), B, Lp, len_keep,
+                               _stream()), "ucfvit_mae_mask")
+    return ids_shuffle, ids_restore, mask
+
+
+def gather_rows(src, idx, R, idx_stride):
+    """src [B,L,D]; idx int64 with row stride idx_stride; -> [B,R,D]"""
+    L = _l.load()
+    _chk(src, "gather_rows.src")
+    B, Lp, D = src.shape
+    out = torch.empty((B, R, D), dtype=src.dtype, device=src.device)
+    _l.check(L.ucfvit_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), B, Lp, R, D, idx_stride, dt(src), _stream()),
+             "ucfvit_gather_rows")
+    return out
+
+
+def scatter_rows(dout, idx, Lp, idx_stride):
+    L = _l.load()
+    _chk(dout, "scatter_rows.dout")
+    B, R, D = dout.shape
+    dsrc = torch.empty((B, Lp, D), dtype=dout.dtype, device=dout.device)
+    _l.check(L.ucfvit_scatter_rows(dout.data_ptr(), idx.data_ptr(), dsrc.data_ptr(), B, Lp, R, D, idx_stride, dt(dout), _stream()),
+             "ucfvit_scatter_rows")
+    return dsrc
+
+
+def unshuffle_fwd(x, mask_token, ids_restore, pos):
+    """x [B,R,D], mask_token [D], ids_restore [B,L] int64, pos [L,D] or None -> [B,L,D]"""
+    L = _l.load()
+    _chk(x, "unshuffle.x")
+    B, R, D = x.shape
+    Lp = ids_restore.shape[1]
+    out = torch.empty((B, Lp, D), dtype=x.dtype, device=x.device)
+    _l.check(L.ucfvit_unshuffle_fwd(x.data_ptr(), mask_token.data_ptr(), ids_restore.data_ptr(), _p(pos), out.data_ptr(), B, Lp, R, D,
+                                    dt(x), _stream()), "ucfvit_unshuffle_fwd")
+    return out
+
+
+def unshuffle_bwd(dout, ids_restore, R, want_pos, dmask=None, dpos=None, accumulate=False):
+    L = _l.load()
+    _chk(dout, "unshuffle_bwd.dout")
+    B, Lp, D = dout.shape
+    dev = dout.device
+    dx = torch.empty((B, R, D), dtype=dout.dtype, device=dev)
+    if dmask is None:
+        dmask = torch.empty(D, dtype=torch.float32, device=dev)
+    if want_pos and dpos is None:
+        dpos = torch.empty((Lp, D), dtype=torch.float32, device=dev)
+    ws = workspace(L.ucfvit_unshuffle_bwd_workspace(B, D), dev)
+    _l.check(L.ucfvit_unshuffle_bwd(dout.data_ptr(), ids_restore.data_ptr(), dx.data_ptr(), dmask.data_ptr(), _p(dpos) if want_pos else None,
+                                    B, Lp, R, D, 1 if accumulate else 0, ws.data_ptr(), dt(dout), _stream()), "ucfvit_unshuffle_bwd")
+    return dx, dmask, dpos
+
+
+def patch_mse(pred, img, p, mask=None, grad_scale=1.0, want_grad=True):
+    """pred [B,L,P]; img fp32 NCHW(D); mask fp32 [B,L] or None -> (loss scalar fp32, dpred or None)"""
+    L = _l.load()
+    _chk(pred, "patch_mse.pred"), _chk(img, "patch_mse.img")
+    B, C = img.shape[0], img.shape[1]
+    sp = list(img.shape[2:])
+    nd = len(sp)
+    dims = (ctypes.c_int64 * 3)(*(sp + [1] * (3 - nd)))
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    ws = workspace(4 * 2049, pred.device)
+    _l.check(L.ucfvit_patch_mse(pred.data_ptr(), img.data_ptr(), _p(mask), loss.data_ptr(), _p(dpred), B, C, dims, nd, p, grad_scale,
+                                ws.data_ptr(), dt(pred), _stream()), "ucfvit_patch_mse")
+    return loss, dpred
+
+
+# ------------------------------------------------------------------------------------------------ optimizer / casts
+def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    L = _l.load()
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _l.check(L.ucfvit_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow), p.numel(), lr, beta1, beta2, eps,
+                            weight_decay, bc1, bc2, grad_scale, dt(g), _stream()), "ucfvit_adamw")
+
+
+def cast(src, dst, scale=1.0):
+    L = _l.load()
+    _l.check(L.ucfvit_cast(src.data_ptr(), dst.data_ptr(), src.numel(), dt(src), dt(dst), scale, _stream()), "ucfvit_cast")
+    return dst

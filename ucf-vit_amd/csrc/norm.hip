@@ -1,0 +1,348 @@
+// LayerNorm forward/backward and column sums (bias gradients) for gfx950.  HBM-bound kernels:
+// one wave (64 lanes) per row, 16-byte vector loads, fp32 statistics, wavefront shuffle reductions,
+// deterministic two-stage reductions for the parameter gradients (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;  // 4 waves = 4 rows in flight per workgroup
+
+// ---------------------------------------------------------------------------------------------------
+// forward: y = (x - mean) * rstd * gamma + beta ; two-pass (mean, then centred variance) on register-cached rows
+template <typename T, int NV>  // NV = 16-B vectors per lane (row length <= 64*NV*EPV)
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                            const T* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                            int D, float eps) {
+    constexpr int EPV = Vec16<T>::N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D / EPV;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const T* xr = x + row * D;
+        Vec16<T> xv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                xv[i] = *reinterpret_cast<const Vec16<T>*>(xr + v * EPV);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) s += xv[i].get(e);
+            }
+        }
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float d = xv[i].get(e) - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+        T* yr = y + row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                const Vec16<T> gv = *reinterpret_cast<const Vec16<T>*>(gamma + v * EPV);
+                const Vec16<T> bv = *reinterpret_cast<const Vec16<T>*>(beta + v * EPV);
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o.set(e, (xv[i].get(e) - mu) * rs * gv.get(e) + bv.get(e));
+                *reinterpret_cast<Vec16<T>*>(yr + v * EPV) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma ; per-workgroup partial dgamma/dbeta
+template <typename T, int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int D) {
+    constexpr int EPV = Vec16<T>::N;
+    __shared__ float red[4][64 * 8 + 8];  // cross-wave reduction staging, one 16-B vector slot (as fp32 x EPV) at a time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D / EPV;
+    float dg[NV][EPV], db[NV][EPV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) dg[i][e] = db[i][e] = 0.f;
+    Vec16<T> gv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nvec) gv[i] = *reinterpret_cast<const Vec16<T>*>(gamma + v * EPV);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        Vec16<T> xv[NV], dv[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                xv[i] = *reinterpret_cast<const Vec16<T>*>(x + row * D + v * EPV);
+                dv[i] = *reinterpret_cast<const Vec16<T>*>(dy + row * D + v * EPV);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float xh = (xv[i].get(e) - mu) * rs;
+                    const float d = dv[i].get(e);
+                    const float g = d * gv[i].get(e);
+                    s1 += g;
+                    s2 += g * xh;
+                    dg[i][e] += d * xh;
+                    db[i][e] += d;
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                Vec16<T> o, rv;
+                if (dres) rv = *reinterpret_cast<const Vec16<T>*>(dres + row * D + v * EPV);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float xh = (xv[i].get(e) - mu) * rs;
+                    const float g = dv[i].get(e) * gv[i].get(e);
+                    float r = rs * (g - c1 - xh * c2);
+                    if (dres) r += rv.get(e);  // fused residual-branch gradient
+                    o.set(e, r);
+                }
+                *reinterpret_cast<Vec16<T>*>(dx + row * D + v * EPV) = o;
+            }
+        }
+    }
+    // reduce the 4 waves' column partials through LDS, then one row of `partial` per workgroup: [grid][2][D]
+    float* pg = partial + (int64_t)blockIdx.x * 2 * D;
+    float* pb = pg + D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) red[wave][lane * EPV + e] = which ? db[i][e] : dg[i][e];
+            __syncthreads();
+            if (wave == 0 && v < nvec) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float t = red[0][lane * EPV + e] + red[1][lane * EPV + e] + red[2][lane * EPV + e] + red[3][lane * EPV + e];
+                    (which ? pb : pg)[v * EPV + e] = t;
+                }
+            }
+        }
+    }
+}
+
+// out[j] (+)= sum_b partial[b][j], j in [0, W)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
+                                       int nblocks, int W0, int accumulate) {
+    // partial rows are [2][W0]: first W0 -> out0, next W0 -> out1 (out1 may be NULL: then rows are [1][W0])
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = out1 ? 2 * W0 : W0;
+    if (j >= W) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * W + j];
+    float* o = (j < W0) ? (out0 + j) : (out1 + (j - W0));
+    *o = accumulate ? (*o + s) : s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column sums: workgroup = 16 column-lanes (16 B each) x 16 row-groups; grid.y row chunks -> partial[chunk][N]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t M, int N,
+                                                     int64_t ldx, int rows_per_chunk) {
+    constexpr int EPV = Vec16<T>::N;
+    __shared__ float red[16][16 * 8 + 4];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = (blockIdx.x * 16 + cl) * EPV;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r_end = min(M, r_begin + rows_per_chunk);
+    float acc[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+    if (col < N) {
+        for (int64_t r = r_begin + rg; r < r_end; r += 16) {
+            const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + r * ldx + col);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) acc[e] += v.get(e);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) red[rg][cl * EPV + e] = acc[e];
+    __syncthreads();
+    if (rg == 0 && col < N) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k][cl * EPV + e];
+            partial[(int64_t)blockIdx.y * N + col + e] = s;
+        }
+    }
+}
+
+template <typename T>
+__global__ void colsum_scalar_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int N, int64_t ldx,
+                                     int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int64_t r = 0; r < M; ++r) s += to_f32<T>(x[r * ldx + n]);
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+inline int colsum_chunks(int64_t M) {
+    int64_t c = (M + 255) / 256;
+    if (c > 64) c = 64;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+inline int ln_grid(int64_t rows) {
+    int64_t g = (rows + 3) / 4;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename T> int ln_nv(int64_t D) {
+    constexpr int EPV = 16 / sizeof(T);
+    if (D % EPV) return -1;
+    const int64_t nvec = D / EPV;
+    if (nvec <= 64) return 1;
+    if (nvec <= 128) return 2;
+    if (nvec <= 256) return 4;
+    if (nvec <= 512) return 8;
+    return -1;
+}
+
+template <typename T>
+int ln_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int64_t rows, int64_t D,
+             float eps, hipStream_t s) {
+    const int nv = ln_nv<T>(D);
+    UCF_CHECK_ARG(nv > 0, "ucfvit_layernorm_fwd: D=%lld must be a multiple of %d and <= %d", (long long)D, (int)(16 / sizeof(T)),
+                  (int)(512 * 16 / sizeof(T)));
+    const dim3 grid(ln_grid(rows)), block(LN_THREADS);
+#define LN_FWD(NVV)                                                                                                        \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), grid, block, 0, s, (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, mean, \
+                       rstd, rows, (int)D, eps)
+    switch (nv) {
+        case 1: LN_FWD(1); break;
+        case 2: LN_FWD(2); break;
+        case 4: LN_FWD(4); break;
+        default: LN_FWD(8); break;
+    }
+#undef LN_FWD
+    UCF_LAUNCH_CHECK("ucfvit_layernorm_fwd");
+    return UCFVIT_OK;
+}
+
+template <typename T>
+int ln_bwd_t(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+             float* dbeta, int64_t rows, int64_t D, int accumulate, void* ws, hipStream_t s) {
+    const int nv = ln_nv<T>(D);
+    UCF_CHECK_ARG(nv > 0 && nv <= 4, "ucfvit_layernorm_bwd: D=%lld must be a multiple of %d and <= %d", (long long)D,
+                  (int)(16 / sizeof(T)), (int)(256 * 16 / sizeof(T)));
+    const int g = ln_grid(rows);
+    const dim3 grid(g), block(LN_THREADS);
+#define LN_BWD(NVV)                                                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)gamma, mean, rstd, \
+                       (const T*)dres, (T*)dx, (float*)ws, rows, (int)D)
+    switch (nv) {
+        case 1: LN_BWD(1); break;
+        case 2: LN_BWD(2); break;
+        default: LN_BWD(4); break;
+    }
+#undef LN_BWD
+    UCF_LAUNCH_CHECK("ucfvit_layernorm_bwd");
+    const int W = 2 * (int)D;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, g, (int)D,
+                       accumulate);
+    UCF_LAUNCH_CHECK("ucfvit_layernorm_bwd(reduce)");
+    return UCFVIT_OK;
+}
+
+}  // namespace
+
+extern "C" int ucfvit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                    int64_t rows, int64_t D, float eps, int dtype, void* stream) {
+    UCF_CHECK_ARG(x && gamma && beta && y && mean && rstd, "ucfvit_layernorm_fwd: null pointer");
+    UCF_CHECK_ARG(rows >= 0 && D > 0, "ucfvit_layernorm_fwd: bad shape rows=%lld D=%lld", (long long)rows, (long long)D);
+    UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(y) && ucf_is_aligned16(gamma) && ucf_is_aligned16(beta),
+                  "ucfvit_layernorm_fwd: pointers must be 16-byte aligned");
+    if (rows == 0) return UCFVIT_OK;
+    if (dtype == UCFVIT_F32) return ln_fwd_t<float>(x, gamma, beta, y, mean, rstd, rows, D, eps, (hipStream_t)stream);
+    if (dtype == UCFVIT_BF16) return ln_fwd_t<bf16>(x, gamma, beta, y, mean, rstd, rows, D, eps, (hipStream_t)stream);
+    ucfvit_set_error("ucfvit_layernorm_fwd: bad dtype %d", dtype);
+    return UCFVIT_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t ucfvit_layernorm_bwd_workspace(int64_t rows, int64_t D) {
+    return (int64_t)ln_grid(rows) * 2 * D * (int64_t)sizeof(float);
+}
+
+extern "C" int ucfvit_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                                    const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, int accumulate,
+                                    void* workspace, int dtype, void* stream) {
+    UCF_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "ucfvit_layernorm_bwd: null pointer");
+    UCF_CHECK_ARG(rows > 0 && D > 0, "ucfvit_layernorm_bwd: bad shape");
+    UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(dy) && ucf_is_aligned16(dx) && ucf_is_aligned16(gamma) && ucf_is_aligned16(dres),
+                  "ucfvit_layernorm_bwd: pointers must be 16-byte aligned");
+    if (dtype == UCFVIT_F32)
+        return ln_bwd_t<float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, accumulate, workspace, (hipStream_t)stream);
+    if (dtype == UCFVIT_BF16)
+        return ln_bwd_t<bf16>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, accumulate, workspace, (hipStream_t)stream);
+    ucfvit_set_error("ucfvit_layernorm_bwd: bad dtype %d", dtype);
+    return UCFVIT_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t ucfvit_colsum_workspace(int64_t M, int64_t N) { return (int64_t)colsum_chunks(M) * N * (int64_t)sizeof(float); }
+
+extern "C" int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate, void* workspace,
+                             int dtype, void* stream) {
+    UCF_CHECK_ARG(x && out, "ucfvit_colsum: null pointer");
+    UCF_CHECK_ARG(M >= 0 && N > 0 && ldx >= N, "ucfvit_colsum: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int epv = dtype == UCFVIT_F32 ? 4 : 8;
+    UCF_CHECK_ARG(dtype == UCFVIT_F32 || dtype == UCFVIT_BF16, "ucfvit_colsum: bad dtype %d", dtype);
+    const bool vec = ucf_is_aligned16(x) && (N % epv == 0) && (ldx % epv == 0) && workspace && M > 0;
+    if (!vec) {
+        if (dtype == UCFVIT_F32)
+            hipLaunchKernelGGL(colsum_scalar_kernel<float>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const float*)x, out,
+                               M, (int)N, ldx, accumulate);
+        else
+            hipLaunchKernelGGL(colsum_scalar_kernel<bf16>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const bf16*)x, out, M,
+                               (int)N, ldx, accumulate);
+        UCF_LAUNCH_CHECK("ucfvit_colsum(scalar)");
+        return UCFVIT_OK;
+    }
+    const int chunks = colsum_chunks(M);
+    const int rpc = (int)((M + chunks - 1) / chunks);
+    const dim3 grid((unsigned)((N / epv + 15) / 16), chunks);
+    if (dtype == UCFVIT_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)workspace, M, (int)N, ldx, rpc);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (float*)workspace, M, (int)N, ldx, rpc);
+    UCF_LAUNCH_CHECK("ucfvit_colsum");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const float*)workspace, out,
+                       (float*)nullptr, chunks, (int)N, accumulate);
+    UCF_LAUNCH_CHECK("ucfvit_colsum(reduce)");
+    return UCFVIT_OK;
+}
