@@ -1,0 +1,143 @@
+"""GPU parity tests of whole models on the HIP path against reference-generated golden vectors: ViT (small and the
+ViT-Tiny/16 catsdogs config of BASELINE.json configs[0]), MAE, and a 5-step AdamW training trajectory."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from det_weights import det_state_dict, proj_vector
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+VARS = ["red", "green", "blue"]
+
+
+def build(cls, kw, seed, dtype=torch.float32):
+    m = cls(**kw)
+    m.load_state_dict(det_state_dict(m, seed))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    return m
+
+
+VIT_KW = dict(img_size=[32, 32], patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=2, num_heads=2)
+MAE_KW = dict(img_size=[32, 32], patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2, class_token=False, weight_init='skip',
+              mask_ratio=0.75, linear_decoder=False, decoder_depth=1, decoder_embed_dim=32, decoder_num_heads=1, mlp_ratio_decoder=4.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_vit_small_vs_reference(dtype, tol):
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    g = load_golden("model_vit_small.npz")
+    m = build(VIT, VIT_KW, 21, dtype)
+    out = m(g["x"].to(DEV), VARS)
+    loss = cross_entropy_loss(out, g["labels"].to(DEV))
+    loss.backward()
+    assert out.dtype == dtype
+    assert rel_err(out.float(), g["logits"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad, g["g." + k]) < tol, k
+    # gradients were written by the kernels straight into the flat buffer (no copies)
+    st = m._ucf_store
+    for p, o in zip(st.params, st.offsets):
+        assert p.grad.data_ptr() == st.flat_g.data_ptr() + 4 * o
+
+
+def test_vit_tiny_config_T_vs_reference():
+    """BASELINE.json configs[0]: ViT-Tiny/16 on catsdogs-shaped input (256x256, pixels 0..255, 2 classes), fp32"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.fused_attn import FusedAttn
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    g = load_golden("model_vit_tiny_catsdogs.npz")
+    m = build(VIT, dict(img_size=[256, 256], patch_size=16, in_chans=3, num_classes=2, embed_dim=192, depth=12, num_heads=3,
+                        FusedAttn_option=FusedAttn.DEFAULT), 23)
+    out = m(g["x"].to(DEV), VARS)
+    loss = cross_entropy_loss(out, g["labels"].to(DEV))
+    loss.backward()
+    assert rel_err(out, g["logits"]) < 1e-3
+    assert abs(loss.item() - g["loss"].item()) < 1e-3 * max(1.0, abs(g["loss"].item()))
+    for i, (k, p) in enumerate(m.named_parameters()):
+        gn_ref = g["gn." + k].item()
+        gn = p.grad.double().norm().item()
+        assert abs(gn - gn_ref) <= 1e-3 * max(gn_ref, 1e-12), k
+        gp = (p.grad.double().cpu() * proj_vector(p.shape, i).double()).sum().item()
+        assert abs(gp - g["gp." + k].item()) <= 1e-3 * max(gn_ref * math.sqrt(p.numel()), 1e-12), k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_mae_small_vs_reference(dtype, tol):
+    from UCF_VIT.simple.arch import MAE
+    from UCF_VIT.utils.metrics import patch_mse_loss
+    g = load_golden("model_mae_small.npz")
+    m = build(MAE, MAE_KW, 26, dtype)
+    x = g["x"].to(DEV)
+    pred, mask = m(x, VARS, noise=g["noise"].to(DEV))
+    assert torch.equal(mask.cpu(), g["mask"])                      # bit-exact mask
+    assert rel_err(pred.float(), g["pred"]) < tol
+    loss = patch_mse_loss(pred, x, 8)
+    assert abs(loss.item() - g["loss"].item()) < tol * abs(g["loss"].item())
+    lm = patch_mse_loss(pred.detach(), x, 8, mask)
+    assert abs(lm.item() - g["loss_masked"].item()) < tol * abs(g["loss_masked"].item())
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad, g["g." + k]) < tol, k
+
+
+def test_adamw_trajectory_vs_reference():
+    """5 training steps in the reference loop order (train_class_simple.py:344-357) with the fused AdamW + closed-form schedule"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
+    g = load_golden("traj_vit_small.npz")
+    m = build(VIT, VIT_KW, 31)
+    opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 1e-2)
+    sch = configure_scheduler(opt, 2, 10, 1e-5, 1e-6)
+    for i in range(5):
+        out = m(g["x%d" % i].to(DEV), VARS)
+        loss = cross_entropy_loss(out, g["labels"][i].to(DEV))
+        assert abs(loss.item() - g["losses"][i].item()) < 1e-3 * max(1.0, g["losses"][i].item()), i
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        sch.step()
+    assert "_flat" in opt.state, "fused flat-segment AdamW path was not taken"
+    for k, v in m.state_dict().items():
+        if not k.startswith("token_embeds"):
+            assert rel_err(v, g["final." + k]) < 1e-3, k
+
+
+def test_bf16_shadow_follows_master():
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer
+    g = load_golden("model_vit_small.npz")
+    m = build(VIT, VIT_KW, 21, torch.bfloat16)
+    opt = configure_optimizer(m, 1e-2, 0.9, 0.95, 0.0)
+    x, y = g["x"].to(DEV), g["labels"].to(DEV)
+    for _ in range(2):
+        cross_entropy_loss(m(x, VARS), y).backward()
+        opt.step()
+        opt.zero_grad()
+    st = m._ucf_store
+    assert torch.equal(st.flat_s.float(), st.flat_p.to(torch.bfloat16).float())
+    with torch.no_grad():
+        m.head.weight.mul_(0.5)          # an outside modification bumps the version -> shadow re-cast on next forward
+    m(x, VARS)
+    assert torch.equal(st.flat_s.float(), st.flat_p.to(torch.bfloat16).float())
+
+
+def test_state_dict_layout_matches_reference_listing():
+    from UCF_VIT.simple.arch import MAE, VIT
+    keys = list(VIT(**VIT_KW).state_dict().keys())
+    assert keys[:4] == ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
+    assert "token_embeds.proj.weight" in keys and "head.weight" in keys and "blocks.1.mlp.fc2.bias" in keys
+    mk = set(MAE(**MAE_KW).state_dict().keys())
+    for k in ("mask_token", "decoder_pos_embed", "decoder_embed.weight", "decoder_norm.bias", "decoder_pred.weight",
+              "decoder_blocks.0.attn.qkv.weight"):
+        assert k in mk
