@@ -108,8 +108,15 @@ def test_adamw_trajectory_vs_reference():
         sch.step()
     assert "_flat" in opt.state, "fused flat-segment AdamW path was not taken"
     for k, v in m.state_dict().items():
-        if not k.startswith("token_embeds"):
-            assert rel_err(v, g["final." + k]) < 1e-3, k
+        if k.startswith("token_embeds"):
+            continue
+        ref = g["final." + k]
+        if k.endswith("attn.qkv.bias"):
+            # d(loss)/d(k-bias) is exactly zero in exact arithmetic (softmax shift invariance): its computed gradient is pure
+            # rounding noise which Adam normalises to +-lr steps, in the reference as well -> compare the q and v thirds only
+            D = ref.numel() // 3
+            v, ref = torch.cat([v[:D], v[2 * D:]]), torch.cat([ref[:D], ref[2 * D:]])
+        assert rel_err(v, ref) < 1e-3, k
 
 
 def test_bf16_shadow_follows_master():

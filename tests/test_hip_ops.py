@@ -188,7 +188,7 @@ def test_cross_entropy(dtype):
     gen = torch.Generator().manual_seed(3)
     logits = (torch.randn(37, 1000, generator=gen) * 3).to(dtype)
     labels = torch.randint(0, 1000, (37,), generator=gen)
-    ref_in = logits.float().requires_grad_(True)
+    ref_in = logits.float().clone().requires_grad_(True)
     ref = torch.nn.CrossEntropyLoss()(ref_in, labels)
     ref.backward()
     x = logits.to(DEV).requires_grad_(True)

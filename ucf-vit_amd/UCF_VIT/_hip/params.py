@@ -104,9 +104,6 @@ def ensure_store(module):
     return st
 
 
-_param_shadow_cache = {}
-
-
 def compute_param(p, dtype):
     """The tensor the kernels read for parameter `p` in compute dtype `dtype` (fp32 master or bf16 shadow)."""
     if p is None:
@@ -122,13 +119,12 @@ def compute_param(p, dtype):
     # stand-alone module (no flat store): per-parameter shadow keyed by version
     if not p.is_cuda:
         raise RuntimeError("UCF_VIT: parameters must be on the MI355X (cuda) device; there is no CPU path")
-    key = id(p)
-    ent = _param_shadow_cache.get(key)
+    ent = getattr(p, "_ucf_shadow", None)  # lives and dies with the Parameter object
     if ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
         sh = torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
         ops.cast(p.detach().contiguous(), sh)
         ent = (p._version, p.data_ptr(), sh)
-        _param_shadow_cache[key] = ent
+        p._ucf_shadow = ent
     return ent[2]
 
 
