@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 1
+#define UCFVIT_ABI_VERSION 2
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -83,8 +83,12 @@ typedef struct ucfvit_gemm_desc {
     int32_t act;
     int32_t accumulate; /* 1: C += result (gradient accumulation) */
     float alpha;
+    void* workspace;         /* optional fp32 scratch for split-K partial sums (see ucfvit_gemm_workspace), or NULL */
+    int64_t workspace_bytes;
 } ucfvit_gemm_desc;
 
+/* bytes of workspace the split-K path would use for this problem (0: none).  Without it the GEMM still runs, un-split. */
+int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* desc);
 int ucfvit_gemm(const ucfvit_gemm_desc* desc, void* stream);
 
 /* column sums  out[n] (fp32) (+)= sum_m x[m][n]   — bias gradients of every nn.Linear (autograd of :159,190,123,127) */

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libucfvit_hip.so")
@@ -26,6 +26,7 @@ class GemmDesc(Structure):
         ("dtype", c_int32), ("out_dtype", c_int32),
         ("act", c_int32), ("accumulate", c_int32),
         ("alpha", c_float),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -34,6 +35,7 @@ _P, _I64, _I, _F = c_void_p, c_int64, c_int, c_float
 SIGNATURES = {
     "ucfvit_abi_version": (c_int, []),
     "ucfvit_last_error": (c_char_p, []),
+    "ucfvit_gemm_workspace": (c_int64, [POINTER(GemmDesc)]),
     "ucfvit_gemm": (c_int, [POINTER(GemmDesc), _P]),
     "ucfvit_colsum_workspace": (c_int64, [_I64, _I64]),
     "ucfvit_colsum": (c_int, [_P, _P, _I64, _I64, _I64, _I, _P, _I, _P]),

@@ -71,6 +71,12 @@ def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None,
     d.a_layout, d.b_layout = a_layout, b_layout
     d.dtype, d.out_dtype = dt(A), dt(out)
     d.act, d.accumulate, d.alpha = act, 1 if accumulate else 0, alpha
+    d.workspace, d.workspace_bytes = None, 0
+    if act == ACT_NONE and bias is None and residual is None:      # only epilogue-free GEMMs (weight gradients) split K
+        need = L.ucfvit_gemm_workspace(ctypes.byref(d))
+        if need > 0:
+            ws = workspace(need, A.device)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _l.check(L.ucfvit_gemm(ctypes.byref(d), _stream()), "ucfvit_gemm")
     return out
 
@@ -79,7 +85,7 @@ def linear_fwd(x2, w, b=None, act=ACT_NONE, residual=None, aux_out=None, out=Non
     """y[M,N] = act(x2[M,K]·w[N,K]ᵀ + b) + residual   (nn.Linear forward, building_blocks.py:123,127,159,190)"""
     M, K = x2.shape
     N = w.shape[0]
-    return gemm(x2, w, M, N, K, LAYOUT_KC, LAYOUT_KS if False else LAYOUT_KC, out=out, bias=b, residual=residual, act=act,
+    return gemm(x2, w, M, N, K, LAYOUT_KC, LAYOUT_KC, out=out, bias=b, residual=residual, act=act,
                 aux_out=aux_out)
 
 

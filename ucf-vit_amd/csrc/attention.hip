@@ -245,27 +245,30 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     }
 }
 
-// delta[b][h][q] = sum_d dO·O
+// delta[b][h][q] = sum_d dO·O : DH/EPV consecutive lanes share one (token, head) row segment (coalesced 16-B loads)
 template <typename T, int DH>
 __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict__ dout, float* __restrict__ delta, int64_t B, int N, int H) {
     constexpr int EPV = 16 / sizeof(T);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, q, h)
-    if (i >= B * N * H) return;
-    const int h = i % H;
-    const int64_t bq = i / H;
-    const int q = bq % N;
-    const int64_t b = bq / N;
-    const T* o = out + bq * H * DH + h * DH;
-    const T* d = dout + bq * H * DH + h * DH;
+    constexpr int LPR = DH / EPV;  // lanes per (token, head): 4, 8, 16 or 32
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, q, h, piece)
+    const int64_t total = B * N * H * LPR;
     float s = 0.f;
-#pragma unroll
-    for (int v = 0; v < DH / EPV; ++v) {
-        const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(o + v * EPV);
-        const Vec16<T> c = *reinterpret_cast<const Vec16<T>*>(d + v * EPV);
+    if (i < total) {
+        const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(out + i * EPV);
+        const Vec16<T> c = *reinterpret_cast<const Vec16<T>*>(dout + i * EPV);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) s += a.get(e) * c.get(e);
     }
-    delta[(b * H + h) * N + q] = s;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (i < total && (threadIdx.x & (LPR - 1)) == 0) {
+        const int64_t bqh = i / LPR;
+        const int h = bqh % H;
+        const int64_t bq = bqh / H;
+        const int q = bq % N;
+        const int64_t b = bq / N;
+        delta[(b * H + h) * N + q] = s;
+    }
 }
 
 // ===================================================================================================
@@ -480,7 +483,7 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N
 template <typename T, int DH>
 int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int64_t B, int64_t N,
                     int64_t H, float scale, hipStream_t s) {
-    const int64_t nd = B * N * H;
+    const int64_t nd = B * N * H * (DH / (16 / (int64_t)sizeof(T)));
     hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, B,
                        (int)N, (int)H);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");

@@ -150,17 +150,26 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
     }
 }
 
-// out[j] (+)= sum_b partial[b][j], j in [0, W)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
-                                       int nblocks, int W0, int accumulate) {
+// out[j] (+)= sum_b partial[b][j], j in [0, W).  Workgroup = 32 columns x 8 row groups (fixed summation order).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                                              float* __restrict__ out1, int nblocks, int W0, int accumulate) {
     // partial rows are [2][W0]: first W0 -> out0, next W0 -> out1 (out1 may be NULL: then rows are [1][W0])
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cl;
     const int W = out1 ? 2 * W0 : W0;
-    if (j >= W) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * W + j];
-    float* o = (j < W0) ? (out0 + j) : (out1 + (j - W0));
-    *o = accumulate ? (*o + s) : s;
+    if (j < W)
+        for (int b = rg; b < nblocks; b += 8) s += partial[(int64_t)b * W + j];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && j < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        float* o = (j < W0) ? (out0 + j) : (out1 + (j - W0));
+        *o = accumulate ? (*o + t) : t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -217,7 +226,7 @@ inline int colsum_chunks(int64_t M) {
 
 inline int ln_grid(int64_t rows) {
     int64_t g = (rows + 3) / 4;
-    if (g > 1024) g = 1024;
+    if (g > 512) g = 512;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -273,7 +282,7 @@ int ln_bwd_t(const void* dy, const void* x, const void* gamma, const float* mean
 #undef LN_BWD
     UCF_LAUNCH_CHECK("ucfvit_layernorm_bwd");
     const int W = 2 * (int)D;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, g, (int)D,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + 31) / 32), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, g, (int)D,
                        accumulate);
     UCF_LAUNCH_CHECK("ucfvit_layernorm_bwd(reduce)");
     return UCFVIT_OK;
@@ -341,7 +350,7 @@ extern "C" int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, in
     else
         hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (float*)workspace, M, (int)N, ldx, rpc);
     UCF_LAUNCH_CHECK("ucfvit_colsum");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const float*)workspace, out,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, s, (const float*)workspace, out,
                        (float*)nullptr, chunks, (int)N, accumulate);
     UCF_LAUNCH_CHECK("ucfvit_colsum(reduce)");
     return UCFVIT_OK;
