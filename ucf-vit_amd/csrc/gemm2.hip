@@ -12,6 +12,8 @@
 //               the contraction extent must be a multiple of 64 (host-checked, else gemm.hip's v1 kernel runs).
 //   split-K   : gridDim.y K-slices write fp32 partial matrices to a caller workspace; a second kernel sums them in a fixed
 //               order (deterministic) and applies accumulate.  Used when the output has too few tiles to fill 256 CUs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -82,8 +84,23 @@ struct Epi2 {
     int act, accumulate;
     float alpha;
     float* slab;       // split-K: fp32 partial matrices [splits][M][N] (ld = N); NULL when gridDim.y == 1
+    unsigned long long* dbg;  // diagnostic stamps (UCFVIT_GEMM_DBG builds of the bench only); NULL in production
 };
 
+// logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
+__device__ __forceinline__ void tile_origin(int t, int tiles_m, int tiles_n, int BM, int BN, int& m0, int& n0) {
+    constexpr int BAND = 8;
+    const int band_tiles = BAND * tiles_m;
+    const int band = t / band_tiles;
+    const int band_w = min(BAND, tiles_n - band * BAND);
+    const int in_band = t - band * band_tiles;
+    m0 = (in_band / band_w) * BM;
+    n0 = (band * BAND + in_band % band_w) * BN;
+}
+
+// PERSISTENT kernel: gridDim.x workgroups (<= resident capacity) walk the tile list round by round.  The first K-tile of the
+// NEXT output tile is DMA-prefetched during the last K-step of the current one, so neither the prologue latency nor the
+// epilogue (LDS-staged, full-line stores) leaves the MFMA pipe idle for a whole HBM round trip.
 template <int LA, int LB, int BM, int BN, int WM, int WN, typename OutT>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C,
                                                              int M, int N, int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m,
@@ -94,74 +111,91 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int nwg = tiles_m * tiles_n;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    constexpr int BAND = 8;
-    const int band_tiles = BAND * tiles_m;
-    const int band = t / band_tiles;
-    const int band_w = min(BAND, tiles_n - band * BAND);
-    const int in_band = t - band * band_tiles;
-    const int tm = in_band / band_w;
-    const int tn = band * BAND + in_band % band_w;
-    const int m0 = tm * BM, n0 = tn * BN;
-
+    const int G = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
+    const int g = lane >> 4, li = lane & 15;
 
     const int k_begin = blockIdx.y * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
     const int nk = (k_end - k_begin) / BK2;
+    float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
 
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // epilogue staging geometry (wave-private LDS rows inside the just-consumed pipeline buffer)
+    constexpr int PADW = TN + 4;                       // fp32 words per staged row
+    constexpr int LPR = TN / 8;                        // lanes per staged row (8 columns each)
+    constexpr int RPI = 64 / LPR;                      // rows per wave-instruction
+    const int prow = lane / LPR, pcol = (lane % LPR) * 8;
+    static_assert(NWAVES * 16 * PADW * 4 <= BUF, "epilogue staging must fit one pipeline buffer");
 
+    int it = 0;        // running K-tile counter: K-tile `it` lives in pipeline buffer it & 1
+    int m0, n0;
+    {
+        const int first = min(G, nwg);
+        if ((int)blockIdx.x >= first) return;
+        tile_origin(xcd_remap(blockIdx.x, first), tiles_m, tiles_n, BM, BN, m0, n0);
+    }
     issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin, M, smem, wave, lane);
     issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin, N, smem + A_BYTES, wave, lane);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        // K-tile kt has landed (vmcnt(0) of every wave, then the barrier); everyone is done reading the other buffer
-        __syncthreads();
-        const char* bufA = smem + (kt & 1) * BUF;
-        const char* bufB = bufA + A_BYTES;
-        if (kt + 1 < nk) {
-            char* nb = smem + ((kt + 1) & 1) * BUF;
-            issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin + (kt + 1) * BK2, M, nb, wave, lane);
-            issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin + (kt + 1) * BK2, N, nb + A_BYTES, wave, lane);
-        }
+    for (int round = 0;; ++round) {
+        // next tile of this workgroup (if any)
+        int nm0 = 0, nn0 = 0;
+        const int next_base = (round + 1) * G;
+        const int next_cnt = min(G, nwg - next_base);
+        const bool has_next = (int)blockIdx.x < next_cnt;
+        if (has_next) tile_origin(next_base + xcd_remap(blockIdx.x, next_cnt), tiles_m, tiles_n, BM, BN, nm0, nn0);
+
+        f32x4 acc[FM][FN];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            bf16x8 fb[FN];
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = load_frag2<LB, BN>(bufB, wn + 16 * j, c, lane);
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            // K-tile `it` has landed (vmcnt(0) of every wave, then the barrier); everyone is done with the other buffer
+            __syncthreads();
+            const char* bufA = smem + (it & 1) * BUF;
+            const char* bufB = bufA + A_BYTES;
+            char* nb = smem + ((it + 1) & 1) * BUF;
+            if (kt + 1 < nk) {
+                issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin + (kt + 1) * BK2, M, nb, wave, lane);
+                issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin + (kt + 1) * BK2, N, nb + A_BYTES, wave, lane);
+            } else if (has_next) {
+                issue_tile<LA, BM, NWAVES>(A, lda, nm0, k_begin, M, nb, wave, lane);
+                issue_tile<LB, BN, NWAVES>(B, ldb, nn0, k_begin, N, nb + A_BYTES, wave, lane);
+            }
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const bf16x8 fa = load_frag2<LA, BM>(bufA, wm + 16 * i, c, lane);
+            for (int c = 0; c < 2; ++c) {
+                bf16x8 fb[FN];
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);  // roles swapped: D[n][m]
+                for (int j = 0; j < FN; ++j) fb[j] = load_frag2<LB, BN>(bufB, wn + 16 * j, c, lane);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const bf16x8 fa = load_frag2<LA, BM>(bufA, wm + 16 * i, c, lane);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);  // roles swapped: D[n][m]
+                }
             }
         }
-    }
 
-    // Epilogue through LDS so every global access is a full 128-B line:
-    //   phase A: v = alpha*acc + bias (fp32) of a 32-row x TN-col strip -> wave-private LDS rows
-    //   phase B: each lane owns 8 consecutive columns of a row: activation / aux / residual / accumulate with 16-B loads, 16-B stores
-    __syncthreads();   // all waves finished reading the pipeline buffers: LDS is reusable
-    constexpr int PADW = TN + 4;                       // fp32 words per staged row (pad keeps 16-B alignment, spreads banks)
-    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * PADW);
-    const int g = lane >> 4, li = lane & 15;
-    constexpr int LPR = TN / 8;                        // lanes per staged row
-    constexpr int RPI = 64 / LPR;                      // rows per wave-instruction
-    const int prow = lane / LPR, pcol = (lane % LPR) * 8;
-    float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
+        // ---- epilogue through LDS so every global access is a full 128-B line ---------------------------------------
+        //   phase A: v = alpha*acc + bias (fp32) of a 16-row x TN-col strip -> wave-private LDS rows
+        //   phase B: each lane owns 8 consecutive columns of a row: activation / aux / residual / accumulate, 16-B loads+stores
+        // The staging area is the pipeline buffer of the K-tile just consumed; the other buffer is receiving the next tile's
+        // first K-tile, so only LDS reads (not the DMA) are waited for here: raw barrier, no vmcnt.
+        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        float* stage = reinterpret_cast<float*>(smem + ((it - 1) & 1) * BUF) + wave * (16 * PADW);
 #pragma unroll
-    for (int p = 0; p < FM / 2; ++p) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * p + ii;
+        for (int i = 0; i < FM; ++i) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 f32x4 v = acc[i][j];
@@ -175,76 +209,358 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
                         for (int r = 0; r < 4; ++r) v[r] += b.get(r);
                     }
                 }
-                *reinterpret_cast<f32x4*>(stage + (16 * ii + li) * PADW + 16 * j + 4 * g) = v;
+                *reinterpret_cast<f32x4*>(stage + li * PADW + 16 * j + 4 * g) = v;
             }
-        }
-        // wave-private region: the compiler's lgkmcnt wait orders the ds_writes above before the ds_reads below
+            // wave-private region: LDS executes one wave's DS instructions in order (writes above, reads below, next pass's writes after)
 #pragma unroll
-        for (int rr = 0; rr < 32; rr += RPI) {
-            const int row = rr + prow;
-            const int m = m0 + wm + 32 * p + row;
-            const int n = n0 + wn + pcol;
-            float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol + 4);
+            for (int rr = 0; rr < 16; rr += RPI) {
+                const int row = rr + prow;
+                const int m = m0 + wm + 16 * i + row;
+                const int n = n0 + wn + pcol;
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol + 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = lo[r];
-                v[4 + r] = hi[r];
-            }
-            if (m >= M || n >= N) continue;     // N % 8 == 0 on this path: the 8 columns are all in or all out
-            if (slab) {
-                *reinterpret_cast<f32x4*>(slab + (int64_t)m * N + n) = lo;
-                *reinterpret_cast<f32x4*>(slab + (int64_t)m * N + n + 4) = hi;
-                continue;
-            }
-            if (ep.act == UCFVIT_ACT_GELU) {
-                if (ep.aux_out) {
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = lo[r];
+                    v[4 + r] = hi[r];
+                }
+                if (m >= M || n >= N) continue;     // N % 8 == 0 on this path: the 8 columns are all in or all out
+                if (slab) {
+                    *reinterpret_cast<f32x4*>(slab + (int64_t)m * N + n) = lo;
+                    *reinterpret_cast<f32x4*>(slab + (int64_t)m * N + n + 4) = hi;
+                    continue;
+                }
+                if (ep.act == UCFVIT_ACT_GELU) {
+                    if (ep.aux_out) {
+                        Vec16<bf16> o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+                        *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+                } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
+                    const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(h.get(r));
+                }
+                if (ep.residual) {
+                    const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
+                }
+                OutT* cp = C + (int64_t)m * ep.ldc + n;
+                if constexpr (sizeof(OutT) == 2) {
+                    if (ep.accumulate) {
+                        const Vec16<bf16> old = *reinterpret_cast<const Vec16<bf16>*>(cp);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += old.get(r);
+                    }
                     Vec16<bf16> o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                    *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                    *reinterpret_cast<Vec16<bf16>*>(cp) = o;
+                } else {
+                    f32x4 o0, o1;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
+                    for (int r = 0; r < 4; ++r) {
+                        o0[r] = v[r];
+                        o1[r] = v[4 + r];
+                    }
+                    if (ep.accumulate) {
+                        o0 += *reinterpret_cast<const f32x4*>(cp);
+                        o1 += *reinterpret_cast<const f32x4*>(cp + 4);
+                    }
+                    *reinterpret_cast<f32x4*>(cp) = o0;
+                    *reinterpret_cast<f32x4*>(cp + 4) = o1;
                 }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
-            } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
-                const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(h.get(r));
-            }
-            if (ep.residual) {
-                const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
-            }
-            OutT* cp = C + (int64_t)m * ep.ldc + n;
-            if constexpr (sizeof(OutT) == 2) {
-                if (ep.accumulate) {
-                    const Vec16<bf16> old = *reinterpret_cast<const Vec16<bf16>*>(cp);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += old.get(r);
-                }
-                Vec16<bf16> o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                *reinterpret_cast<Vec16<bf16>*>(cp) = o;
-            } else {
-                f32x4 o0, o1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o0[r] = v[r];
-                    o1[r] = v[4 + r];
-                }
-                if (ep.accumulate) {
-                    o0 += *reinterpret_cast<const f32x4*>(cp);
-                    o1 += *reinterpret_cast<const f32x4*>(cp + 4);
-                }
-                *reinterpret_cast<f32x4*>(cp) = o0;
-                *reinterpret_cast<f32x4*>(cp + 4) = o1;
             }
         }
+        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (!has_next) break;
+        m0 = nm0;
+        n0 = nn0;
+    }
+}
+
+// =====================================================================================================================
+// PING-PONG variant of the persistent 256x256x64 kernel (8 waves).  The two wave groups G0 = waves 0-3 (rows 0-127 of the
+// tile) and G1 = waves 4-7 (rows 128-255) — wave w and w+4 share a SIMD — run the SAME program skewed by one barrier
+// interval: while one group is in a MEM interval (DMA issue for the next K-tile + ds_read of a 32-deep fragment set), the
+// other is in a COMPUTE interval (32 MFMAs out of registers), so each SIMD's matrix pipe always has one wave feeding it.
+//
+//   interval 4t+0: G0 MEM(kt,c0) [+ issue DMA of its half of tile kt+1] | G1 COMPUTE(kt-1,c1)
+//   interval 4t+1: G0 COMPUTE(kt,c0)                                    | G1 MEM(kt,c0) [+ issue DMA of its half of tile kt+1]
+//   interval 4t+2: G0 MEM(kt,c1)                                        | G1 COMPUTE(kt,c0)
+//   interval 4t+3: G0 COMPUTE(kt,c1) ; vmcnt(0)                         | G1 MEM(kt,c1) ; vmcnt(0)
+//
+// Every interval ends with one raw s_barrier executed by all 8 waves.  DMA data of tile kt+1 is waited for (vmcnt(0) by the
+// issuing waves, then the barrier) at the end of interval 4t+3, i.e. 3-4 intervals after it was issued and right before its
+// first reader (G0 in interval 4t+4).  A pipeline buffer is overwritten only >= 1 interval after its last ds_read.
+// =====================================================================================================================
+// Per-lane 32-bit byte offsets (row clamp + source-side swizzle folded in) of this wave's 4 DMA pieces of an operand K-tile;
+// the K position is a wave-uniform byte offset added to the (SGPR) base pointer at issue time.
+template <int LAYOUT, int BR>
+__device__ __forceinline__ void half_offsets(unsigned (&off)[4], int64_t ld, int r0, int R, int grp, int w4, int lane) {
+    constexpr int NP = BR / 8, PER = NP / 8;
+    static_assert(PER == 4, "256-wide operand tiles only");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = grp * (NP / 2) + w4 * PER + i;
+        if (LAYOUT == UCFVIT_LAYOUT_KC) {
+            const int row = idx * 8 + (lane >> 3);
+            const int gslot = (lane & 7) ^ (row & 7);
+            int gr = r0 + row;
+            gr = gr < R ? gr : R - 1;
+            off[i] = (unsigned)(((int64_t)gr * ld + gslot * 8) * 2);
+        } else {
+            constexpr int RB = BR * 2, KPP = 1024 / RB;
+            const int krow = idx * KPP + (lane * 16) / RB;
+            const int pbyte = (lane * 16) % RB;
+            const int col = (pbyte ^ ks_swz2(krow)) >> 1;
+            int gc = r0 + col;
+            gc = gc <= R - 8 ? gc : R - 8;
+            off[i] = (unsigned)(((int64_t)krow * ld + gc) * 2);
+        }
+    }
+}
+template <int BR>
+__device__ __forceinline__ void issue_half(const char* __restrict__ base_k, const unsigned (&off)[4], char* lds, int grp, int w4) {
+    constexpr int NP = BR / 8, PER = NP / 8;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = grp * (NP / 2) + w4 * PER + i;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base_k + off[i]), (lptr_t)(lds + idx * 1024), 16, 0, 0);
+    }
+}
+// wave-uniform byte offset of K position k0 for an operand
+template <int LAYOUT> __device__ __forceinline__ int64_t k_byte_off(int k0, int64_t ld) {
+    return LAYOUT == UCFVIT_LAYOUT_KC ? (int64_t)k0 * 2 : (int64_t)k0 * ld * 2;
+}
+
+#define PP_BARRIER()                              \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_s_barrier();             \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+#define PP_WAIT_DMA()                                      \
+    do {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+
+template <int LA, int LB, typename OutT>
+__global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C, int M, int N,
+                                                     int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m, int tiles_n, int k_per_split) {
+    constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nwg = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = grp * TM, wn = w4 * TN;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int k_begin = blockIdx.y * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    const int nk = (k_end - k_begin) / BK2;
+    float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
+
+    constexpr int PADW = TN + 4, LPR = TN / 8, RPI = 64 / LPR;
+    const int prow = lane / LPR, pcol = (lane % LPR) * 8;
+
+    int it = 0;
+    int m0, n0;
+    {
+        const int first = min(G, nwg);
+        if ((int)blockIdx.x >= first) return;
+        tile_origin(xcd_remap(blockIdx.x, first), tiles_m, tiles_n, BM, BN, m0, n0);
+    }
+    // prologue: both groups issue their halves of the first K-tile, wait, barrier
+    const char* Ab = reinterpret_cast<const char*>(A);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    unsigned offA[4], offB[4];
+    half_offsets<LA, BM>(offA, lda, m0, M, grp, w4, lane);
+    half_offsets<LB, BN>(offB, ldb, n0, N, grp, w4, lane);
+    issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, smem, grp, w4);
+    issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, smem + A_BYTES, grp, w4);
+    PP_WAIT_DMA();
+    PP_BARRIER();
+
+    bf16x8 fa[FM], fb[FN];   // one 32-deep fragment set (48 VGPRs)
+
+    for (int round = 0;; ++round) {
+        int nm0 = 0, nn0 = 0;
+        const int next_base = (round + 1) * G;
+        const int next_cnt = min(G, nwg - next_base);
+        const bool has_next = (int)blockIdx.x < next_cnt;
+        if (has_next) tile_origin(next_base + xcd_remap(blockIdx.x, next_cnt), tiles_m, tiles_n, BM, BN, nm0, nn0);
+
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define PP_READ(bufA_, bufB_, c_)                                                              \
+    do {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = load_frag2<LB, BN>(bufB_, wn + 16 * j, c_, lane); \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) fa[i] = load_frag2<LA, BM>(bufA_, wm + 16 * i, c_, lane); \
+    } while (0)
+#define PP_COMPUTE()                                                                           \
+    do {                                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                         \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                         \
+    } while (0)
+#define PP_ISSUE_NEXT(kt_)                                                                     \
+    do {                                                                                       \
+        char* nb = smem + ((it + 1) & 1) * BUF;                                                \
+        if ((kt_) + 1 < nk) {                                                                  \
+            issue_half<BM>(Ab + k_byte_off<LA>(k_begin + ((kt_) + 1) * BK2, lda), offA, nb, grp, w4);            \
+            issue_half<BN>(Bb + k_byte_off<LB>(k_begin + ((kt_) + 1) * BK2, ldb), offB, nb + A_BYTES, grp, w4);  \
+        } else if (has_next) {                                                                 \
+            half_offsets<LA, BM>(offA, lda, nm0, M, grp, w4, lane);  /* offsets now belong to the next tile */ \
+            half_offsets<LB, BN>(offB, ldb, nn0, N, grp, w4, lane);                            \
+            issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, nb, grp, w4);              \
+            issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, nb + A_BYTES, grp, w4);    \
+        }                                                                                      \
+    } while (0)
+
+        // One program for both groups; G1 runs it one barrier interval behind G0 (extra barrier before / after the loop).
+        if (grp == 1) PP_BARRIER();
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const char* bufA = smem + (it & 1) * BUF;
+            const char* bufB = bufA + A_BYTES;
+            PP_ISSUE_NEXT(kt);              // MEM(c0): DMA of this group's half of the next K-tile + fragment reads
+            PP_READ(bufA, bufB, 0);
+            PP_BARRIER();
+            PP_COMPUTE();                   // COMPUTE(c0)
+            PP_BARRIER();
+            PP_READ(bufA, bufB, 1);         // MEM(c1)
+            if (grp == 1) PP_WAIT_DMA();    // G1's DMA (issued 2 intervals ago) must be visible before G0's next MEM(c0)
+            PP_BARRIER();
+            PP_COMPUTE();                   // COMPUTE(c1)
+            if (grp == 0) PP_WAIT_DMA();    // G0's DMA was issued 3 intervals ago
+            PP_BARRIER();
+        }
+        if (grp == 0) PP_BARRIER();
+#undef PP_READ
+#undef PP_COMPUTE
+#undef PP_ISSUE_NEXT
+
+        // ---- epilogue (same as gemm2_kernel): staging area = the pipeline buffer of the K-tile just consumed ----------
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        float* stage = reinterpret_cast<float*>(smem + ((it - 1) & 1) * BUF) + wave * (16 * PADW);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 v = acc[i][j];
+                if (!slab) {
+                    const int n = n0 + wn + 16 * j + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= ep.alpha;
+                    if (ep.bias && n < N) {
+                        const Vec4<bf16> b = *reinterpret_cast<const Vec4<bf16>*>(ep.bias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += b.get(r);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(stage + li * PADW + 16 * j + 4 * g) = v;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; rr += RPI) {
+                const int row = rr + prow;
+                const int m = m0 + wm + 16 * i + row;
+                const int n = n0 + wn + pcol;
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = lo[r];
+                    v[4 + r] = hi[r];
+                }
+                if (m >= M || n >= N) continue;
+                if (slab) {
+                    *reinterpret_cast<f32x4*>(slab + (int64_t)m * N + n) = lo;
+                    *reinterpret_cast<f32x4*>(slab + (int64_t)m * N + n + 4) = hi;
+                    continue;
+                }
+                if (ep.act == UCFVIT_ACT_GELU) {
+                    if (ep.aux_out) {
+                        Vec16<bf16> o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+                        *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = o.get(r);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+                } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
+                    const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(h.get(r));
+                }
+                if (ep.residual) {
+                    const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
+                }
+                OutT* cp = C + (int64_t)m * ep.ldc + n;
+                if constexpr (sizeof(OutT) == 2) {
+                    if (ep.accumulate) {
+                        const Vec16<bf16> old = *reinterpret_cast<const Vec16<bf16>*>(cp);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += old.get(r);
+                    }
+                    Vec16<bf16> o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+                    *reinterpret_cast<Vec16<bf16>*>(cp) = o;
+                } else {
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o0[r] = v[r];
+                        o1[r] = v[4 + r];
+                    }
+                    if (ep.accumulate) {
+                        o0 += *reinterpret_cast<const f32x4*>(cp);
+                        o1 += *reinterpret_cast<const f32x4*>(cp + 4);
+                    }
+                    *reinterpret_cast<f32x4*>(cp) = o0;
+                    *reinterpret_cast<f32x4*>(cp + 4) = o1;
+                }
+            }
+        }
+        if (!has_next) break;
+        m0 = nm0;
+        n0 = nn0;
+        // the next tile's first K-tile was issued during the last K-tile and waited for (vmcnt(0) + barrier) at its end;
+        // the epilogue's LDS staging of every wave must be finished before that buffer's partner is refilled:
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -286,7 +602,12 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
     const int64_t t128 = ((d->M + 127) / 128) * ((d->N + 127) / 128);
     const bool plain_epi = !d->bias && !d->residual && !d->aux_in && !d->aux_out && d->act == UCFVIT_ACT_NONE;
     p->splits = 1;
-    if (t256 >= 192) {
+    static int force_small = -1;
+    if (force_small < 0) {
+        const char* e = getenv("UCFVIT_GEMM_SMALL");
+        force_small = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (t256 >= 192 && !force_small) {
         p->big = 1;
     } else {
         p->big = 0;
@@ -321,7 +642,12 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, p.splits), dim3(WM * WN * 64), smem, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C,
+    // persistent grid: one workgroup per CU for the 128-KiB-LDS tile, two for the 64-KiB one (split-K slices multiply the grid)
+    const int ntiles = tiles_m * tiles_n;
+    int cap = (BM == 256 ? 256 : 512) / p.splits;
+    if (cap < 1) cap = 1;
+    const int gx = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL(kern, dim3(gx, p.splits), dim3(WM * WN * 64), smem, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C,
                        (int)d->M, (int)d->N, (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n, p.k_per_split);
     UCF_LAUNCH_CHECK("ucfvit_gemm(v2)");
     if (p.splits > 1) {
@@ -336,7 +662,43 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
 }
 
 template <int LA, int LB, typename OutT>
+int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
+    const int tiles_m = (int)((d->M + 255) / 256), tiles_n = (int)((d->N + 255) / 256);
+    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128;
+    auto kern = gemm3_kernel<LA, LB, OutT>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            ucfvit_set_error("ucfvit_gemm: cannot raise dynamic LDS to %zu bytes: %s", smem, hipGetErrorString(e));
+            return UCFVIT_ERR_HIP;
+        }
+        done = true;
+    }
+    const int ntiles = tiles_m * tiles_n;
+    int cap = 256 / p.splits;
+    if (cap < 1) cap = 1;
+    const int gx = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL(kern, dim3(gx, p.splits), dim3(512), smem, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C, (int)d->M, (int)d->N,
+                       (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n, p.k_per_split);
+    UCF_LAUNCH_CHECK("ucfvit_gemm(v3 ping-pong)");
+    return UCFVIT_OK;
+}
+
+static bool pp_enabled() {
+    static int flag = -1;
+    if (flag < 0) {
+        const char* e = getenv("UCFVIT_GEMM_NOPP");
+        flag = (e && e[0] == '1') ? 0 : 1;
+    }
+    return flag == 1;
+}
+
+template <int LA, int LB, typename OutT>
 int dispatch_tile(const ucfvit_gemm_desc* d, const Plan2& p, const Epi2& ep, hipStream_t s) {
+    const int64_t a_bytes = ((d->a_layout == UCFVIT_LAYOUT_KC ? d->M : d->K) * d->lda) * 2;
+    const int64_t b_bytes = ((d->b_layout == UCFVIT_LAYOUT_KC ? d->N : d->K) * d->ldb) * 2;
+    if (p.big && pp_enabled() && a_bytes < (1ll << 32) && b_bytes < (1ll << 32)) return launch3<LA, LB, OutT>(d, p, ep, s);
     if (p.big) return launch2<LA, LB, 256, 256, 2, 4, OutT>(d, p, ep, s);
     return launch2<LA, LB, 128, 128, 2, 2, OutT>(d, p, ep, s);
 }
@@ -387,6 +749,10 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     ep.accumulate = d->accumulate;
     ep.alpha = d->alpha;
     ep.slab = nullptr;
+    {
+        const char* e = getenv("UCFVIT_GEMM_DBG");
+        ep.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
+    }
     if (p.splits > 1) {
         const int64_t need = (int64_t)p.splits * d->M * d->N * (int64_t)sizeof(float);
         if (!d->workspace || d->workspace_bytes < need || !ucf_is_aligned16(d->workspace)) {
