@@ -191,6 +191,12 @@ int ucfvit_adamw(float* p, const void* g, float* m, float* v, void* shadow_bf16,
 /* dtype conversion / scaling helpers (fp32 master → bf16 shadow cast; bf16 gradient transport for the DP all-reduce) */
 int ucfvit_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, float scale, void* stream);
 
+/* Batched 2-D transposes of bf16 matrices inside one flat buffer: the transposed shadow of every nn.Linear weight, so the
+ * data-gradient GEMMs (dx = dy·W, building_blocks.py:123,127,159,190 under autograd) read both operands contraction-contiguous.
+ * table (device): int64 [n_mats][5] = {src_off, dst_off, rows, cols, first_tile} in elements; rows, cols multiples of 8;
+ * a matrix uses ceil(rows/64)*ceil(cols/64) tiles; total_tiles = sum. */
+int ucfvit_transpose_batched(const void* src, void* dst, const int64_t* table, int64_t n_mats, int64_t total_tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

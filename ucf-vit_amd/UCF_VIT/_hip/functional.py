@@ -11,7 +11,7 @@ import torch
 
 from . import ops
 from .lib import ACT_GELU, ACT_NONE
-from .params import compute_param, grad_target
+from .params import compute_param, compute_param_t, grad_target
 
 
 def _as(x, dtype):
@@ -55,6 +55,14 @@ def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None):
     return dx, (None if aw else dg), (None if ab else db)
 
 
+def _dgrad(dy2, p_w, w, aux=None):
+    """dx = dy·W (optionally x gelu'(aux)); uses the transposed weight shadow when the flat store keeps one"""
+    wT = compute_param_t(p_w, dy2.dtype)
+    if wT is not None:
+        return ops.linear_dgrad_t(dy2, wT, act_grad_aux=aux)
+    return ops.linear_dgrad(dy2, w, act_grad_aux=aux)
+
+
 # ---------------------------------------------------------------------------------------------- raw fused sequences
 def _attn_fwd(x2, B, N, H, wqkv, bqkv, wproj, bproj, residual):
     D = x2.shape[1]
@@ -71,11 +79,11 @@ def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_p
     dh = D // H
     g_projw = _wgrad(p_projw, dy2, o) if needs[2] else None
     g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
-    do = ops.linear_dgrad(dy2, wproj)
+    do = _dgrad(dy2, p_projw, wproj)
     dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
     g_qkvw = _wgrad(p_qkvw, dqkv, x2) if needs[0] else None
     g_qkvb = _bgrad(p_qkvb, dqkv) if (p_qkvb is not None and needs[1]) else None
-    dx = ops.linear_dgrad(dqkv, wqkv)
+    dx = _dgrad(dqkv, p_qkvw, wqkv)
     return dx, (g_qkvw, g_qkvb, g_projw, g_projb)
 
 
@@ -90,10 +98,10 @@ def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs):
     h, a = saved
     g_w2 = _wgrad(p_w2, dy2, a) if needs[2] else None
     g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
-    dh = ops.linear_dgrad(dy2, w2, act_grad_aux=h)                     # dgrad fused with gelu'(h)
+    dh = _dgrad(dy2, p_w2, w2, aux=h)                                  # dgrad fused with gelu'(h)
     g_w1 = _wgrad(p_w1, dh, x2) if needs[0] else None
     g_b1 = _bgrad(p_b1, dh) if (p_b1 is not None and needs[1]) else None
-    dx = ops.linear_dgrad(dh, w1)
+    dx = _dgrad(dh, p_w1, w1)
     return dx, (g_w1, g_b1, g_w2, g_b2)
 
 
@@ -120,7 +128,7 @@ class LinearFn(torch.autograd.Function):
         gb = _bgrad(bias, dy2) if (bias is not None and ctx.needs_input_grad[2]) else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _ret_grad(ops.linear_dgrad(dy2, w).view(ctx.in_shape), ctx.in_dtype)
+            dx = _ret_grad(_dgrad(dy2, weight, w).view(ctx.in_shape), ctx.in_dtype)
         return dx, gw, gb, None
 
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "ucfvit_patch_mse": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, POINTER(c_int64), _I, _I64, _F, _P, _I, _P]),
     "ucfvit_adamw": (c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P]),
     "ucfvit_cast": (c_int, [_P, _P, _I64, _I, _I, _F, _P]),
+    "ucfvit_transpose_batched": (c_int, [_P, _P, _P, _I64, _I64, _P]),
 }
 
 _lib = None

@@ -319,3 +319,17 @@ def cast(src, dst, scale=1.0):
     L = _l.load()
     _l.check(L.ucfvit_cast(src.data_ptr(), dst.data_ptr(), src.numel(), dt(src), dt(dst), scale, _stream()), "ucfvit_cast")
     return dst
+
+
+def transpose_batched(src_flat, dst_flat, table, n_mats, total_tiles):
+    L = _l.load()
+    _l.check(L.ucfvit_transpose_batched(src_flat.data_ptr(), dst_flat.data_ptr(), table.data_ptr(), n_mats, total_tiles, _stream()),
+             "ucfvit_transpose_batched")
+
+
+def linear_dgrad_t(dy2, wT, act_grad_aux=None, out=None):
+    """dx[M,K] = dy2[M,N]·W with W given TRANSPOSED (wT [K,N]): both operands contraction-contiguous (fast path)"""
+    M, N = dy2.shape
+    K = wT.shape[0]
+    return gemm(dy2, wT, M, K, N, LAYOUT_KC, LAYOUT_KC, out=out, act=ACT_GELU_GRAD if act_grad_aux is not None else ACT_NONE,
+                aux_in=act_grad_aux)

@@ -48,7 +48,20 @@ class HipParamStore:
         self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.flat_s = None  # bf16 shadow, allocated on first bf16 use
+        self.flat_t = None  # bf16 transposed shadow of the 2-D (nn.Linear) weights, for the data-gradient GEMMs
         self._shadow_sig = None
+        self._t_fresh = False
+        # transposable weights: plain 2-D matrices with both extents >= 128 and multiples of 8
+        rows = []
+        tiles = 0
+        for p, o in zip(self.params, self.offsets):
+            if p.dim() == 2 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0 and min(p.shape) >= 128:
+                r, c = p.shape
+                rows.append([o, o, r, c, tiles])
+                tiles += ((r + 63) // 64) * ((c + 63) // 64)
+                p._ucf_has_t = True
+        self._t_tiles = tiles
+        self._t_table = torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -86,13 +99,23 @@ class HipParamStore:
         if force or sig != self._shadow_sig:
             ops.cast(self.flat_p, self.flat_s)
             self._shadow_sig = sig
+            self._t_fresh = False
+        if not self._t_fresh and self._t_table is not None:
+            if self.flat_t is None:
+                self.flat_t = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+            ops.transpose_batched(self.flat_s, self.flat_t, self._t_table, self._t_table.shape[0], self._t_tiles)
+            self._t_fresh = True
 
     def shadow_view(self, p, o, n):
         return self.flat_s[o:o + n].view(p.shape)
 
     def note_shadow_fresh(self):
-        """called by HipAdamW after a fused update that also wrote the shadow"""
+        """called by HipAdamW after a fused update that also wrote the shadow (the transposed copy follows on the next forward)"""
         self._shadow_sig = self._sig()
+        self._t_fresh = False
+
+    def shadow_t_view(self, p, o, n):
+        return self.flat_t[o:o + n].view(p.shape[1], p.shape[0])
 
 
 def ensure_store(module):
@@ -126,6 +149,16 @@ def compute_param(p, dtype):
         ent = (p._version, p.data_ptr(), sh)
         p._ucf_shadow = ent
     return ent[2]
+
+
+def compute_param_t(p, dtype):
+    """Transposed bf16 shadow [K, N] of a 2-D weight [N, K] if the flat store keeps one (bf16 mode), else None."""
+    if dtype != torch.bfloat16 or not getattr(p, "_ucf_has_t", False):
+        return None
+    slot = getattr(p, "_ucf_slot", None)
+    if slot is None or not slot[0].owns(p, slot[1]) or slot[0].flat_t is None or not slot[0]._t_fresh:
+        return None
+    return slot[0].shadow_t_view(p, slot[1], slot[2])
 
 
 def grad_target(p):

@@ -769,3 +769,61 @@ extern "C" int ucfvit_cast(const void* src, void* dst, int64_t n, int src_dtype,
     UCF_LAUNCH_CHECK("ucfvit_cast");
     return UCFVIT_OK;
 }
+
+// ===================================================================================================
+// Batched 2-D transpose of bf16 matrices living in one flat buffer (the transposed weight shadow used by the
+// data-gradient GEMMs, so they run contraction-contiguous on both operands).  table: int64 [n][5] =
+// {src_off, dst_off, rows, cols, first_tile}; 64x64 tiles through LDS, 16-byte global accesses.
+// ===================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                const int64_t* __restrict__ table, int n_mats) {
+    __shared__ unsigned short tile[64][64 + 8];
+    int lo = 0, hi = n_mats - 1;
+    const int64_t bid = blockIdx.x;
+    while (lo < hi) {  // last matrix whose first_tile <= bid
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 5 + 4] <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* t = table + lo * 5;
+    const int64_t rows = t[2], cols = t[3];
+    const int64_t tiles_c = (cols + 63) / 64;
+    const int64_t lt = bid - t[4];
+    const int64_t r0 = (lt / tiles_c) * 64, c0 = (lt % tiles_c) * 64;
+    const unsigned short* s = src + t[0];
+    unsigned short* d = dst + t[1];
+    // load 64 rows x 64 cols: thread -> (row = tid/8 + 32*i, 8 cols)
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = r0 + tr + 32 * i, c = c0 + tc;
+        if (r < rows && c < cols) {  // cols % 8 == 0 (host-checked)
+            const u32x4 v = *reinterpret_cast<const u32x4*>(s + r * cols + c);
+            *reinterpret_cast<u32x4*>(&tile[tr + 32 * i][tc]) = v;
+        }
+    }
+    __syncthreads();
+    // store transposed: output row = c0 + tr', 8 consecutive output cols = input rows r0 + tc' .. +7
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oc = tr + 32 * i;               // input col within tile = output row
+        const int64_t orow = c0 + oc, ocol = r0 + tc;
+        if (orow < cols && ocol < rows) {         // rows % 8 == 0 (host-checked)
+            unsigned short v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[tc + e][oc];
+            *reinterpret_cast<u32x4*>(d + orow * rows + ocol) = *reinterpret_cast<const u32x4*>(v);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ucfvit_transpose_batched(const void* src, void* dst, const int64_t* table, int64_t n_mats, int64_t total_tiles, void* stream) {
+    UCF_CHECK_ARG(src && dst && table, "ucfvit_transpose_batched: null pointer");
+    UCF_CHECK_ARG(n_mats > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "ucfvit_transpose_batched: bad sizes");
+    UCF_CHECK_ARG(ucf_is_aligned16(src) && ucf_is_aligned16(dst), "ucfvit_transpose_batched: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
+                       (unsigned short*)dst, table, (int)n_mats);
+    UCF_LAUNCH_CHECK("ucfvit_transpose_batched");
+    return UCFVIT_OK;
+}
