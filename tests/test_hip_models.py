@@ -148,3 +148,35 @@ def test_state_dict_layout_matches_reference_listing():
     for k in ("mask_token", "decoder_pos_embed", "decoder_embed.weight", "decoder_norm.bias", "decoder_pred.weight",
               "decoder_blocks.0.attn.qkv.weight"):
         assert k in mk
+
+
+def test_hip_data_parallel_world1_nccl():
+    """the RCCL reducer path (flat-buffer buckets, AVG all-reduce on the nccl backend, end-of-backward stream wait) on one rank"""
+    import os
+    import torch.distributed as dist
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer
+    from UCF_VIT._hip.ddp import HipDataParallel
+    g = load_golden("model_vit_small.npz")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = build(VIT, VIT_KW, 21)
+        ddp = HipDataParallel(m, bucket_mb=0.05)
+        assert len(ddp.buckets) >= 3
+        opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 1e-2)
+        for _ in range(2):
+            out = ddp(g["x"].to(DEV), VARS, None)
+            loss = cross_entropy_loss(out, g["labels"].to(DEV))
+            loss.backward()
+            if _ == 0:
+                for k, p in m.named_parameters():
+                    assert rel_err(p.grad, g["g." + k]) < 1e-3, k
+            opt.step()
+            opt.zero_grad()
+        assert "_flat" in opt.state
+        assert all(k.startswith("module.") for k in ddp.state_dict())
+    finally:
+        dist.destroy_process_group()

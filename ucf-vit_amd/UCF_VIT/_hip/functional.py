@@ -63,20 +63,56 @@ def _dgrad(dy2, p_w, w, aux=None):
     return ops.linear_dgrad(dy2, w, act_grad_aux=aux)
 
 
+class TP:
+    """tensor-parallel (Hybrid-OP) handle: process group, size, rank in group.  group "local" = no collective (the
+    single-GPU shard-equivalence tests sum the partial results themselves)."""
+
+    def __init__(self, group, size):
+        self.group, self.size = group, size
+        if hasattr(group, "tp_rank"):          # in-process stand-in used by the single-GPU equivalence tests
+            self.rank = group.tp_rank
+        elif group is None or isinstance(group, str):
+            self.rank = 0
+        else:
+            self.rank = torch.distributed.get_rank(group)
+
+    def all_reduce(self, t):
+        if self.size <= 1 or self.group is None or isinstance(self.group, str):
+            return t
+        if hasattr(self.group, "all_reduce_sum"):
+            return self.group.all_reduce_sum(t)
+        if t.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+            # test-only transport (several ranks sharing one GPU cannot use RCCL): stage through host memory
+            h = t.detach().float().cpu()
+            torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            t.copy_(h.to(t.dtype))
+            return t
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)   # RCCL, own stream; stream-ordered
+        return t
+
+
 # ---------------------------------------------------------------------------------------------- raw fused sequences
-def _attn_fwd(x2, B, N, H, wqkv, bqkv, wproj, bproj, residual):
-    D = x2.shape[1]
-    dh = D // H
+# With a TP handle the weights are this rank's shards (qkv: 3*D/tp rows = H/tp heads, proj: D/tp columns, fc1: 4D/tp rows,
+# fc2: 4D/tp columns; reference fsdp/building_blocks.py:123-142,169-217): the exit GEMM output is SUM-all-reduced (forward) and
+# the entry gradient is SUM-all-reduced (backward).  The residual is fused on TP rank 0 only, so the sum adds it exactly once;
+# the row-parallel biases are added on every rank like the reference does (SURVEY.md §0, bias counted tp times).
+def _attn_fwd(x2, B, N, H, wqkv, bqkv, wproj, bproj, residual, tp=None):
+    dh = wproj.shape[0] // H
+    Hl = H // tp.size if tp else H
     qkv = ops.linear_fwd(x2, wqkv, bqkv)                               # K4: qkv GEMM + bias
-    o, lse = ops.attention_fwd(qkv, B, N, H, dh, dh ** -0.5)           # K5: fused softmax(QKᵀ)V
+    o, lse = ops.attention_fwd(qkv, B, N, Hl, dh, dh ** -0.5)          # K5: fused softmax(QKᵀ)V over the local heads
+    if tp and tp.rank != 0:
+        residual = None
     y = ops.linear_fwd(o, wproj, bproj, residual=residual)             # K6: proj GEMM + bias (+ residual)
+    if tp:
+        tp.all_reduce(y)                                               # C3: exit all-reduce
     return y, (qkv, o, lse)
 
 
-def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs):
+def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs, tp=None):
     qkv, o, lse = saved
-    D = x2.shape[1]
-    dh = D // H
+    dh = wproj.shape[0] // H
+    H = H // tp.size if tp else H
     g_projw = _wgrad(p_projw, dy2, o) if needs[2] else None
     g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
     do = _dgrad(dy2, p_projw, wproj)
@@ -84,17 +120,23 @@ def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_p
     g_qkvw = _wgrad(p_qkvw, dqkv, x2) if needs[0] else None
     g_qkvb = _bgrad(p_qkvb, dqkv) if (p_qkvb is not None and needs[1]) else None
     dx = _dgrad(dqkv, p_qkvw, wqkv)
+    if tp:
+        tp.all_reduce(dx)                                              # C2: entry gradient all-reduce
     return dx, (g_qkvw, g_qkvb, g_projw, g_projb)
 
 
-def _mlp_fwd(x2, w1, b1, w2, b2, residual):
+def _mlp_fwd(x2, w1, b1, w2, b2, residual, tp=None):
     h = torch.empty((x2.shape[0], w1.shape[0]), dtype=x2.dtype, device=x2.device)
     a = ops.linear_fwd(x2, w1, b1, act=ACT_GELU, aux_out=h)            # K7: fc1 GEMM + bias + erf-GELU (pre-activation kept)
+    if tp and tp.rank != 0:
+        residual = None
     y = ops.linear_fwd(a, w2, b2, residual=residual)                   # K7: fc2 GEMM + bias (+ residual)
+    if tp:
+        tp.all_reduce(y)                                               # C4: exit all-reduce
     return y, (h, a)
 
 
-def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs):
+def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None):
     h, a = saved
     g_w2 = _wgrad(p_w2, dy2, a) if needs[2] else None
     g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
@@ -102,6 +144,8 @@ def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs):
     g_w1 = _wgrad(p_w1, dh, x2) if needs[0] else None
     g_b1 = _bgrad(p_b1, dh) if (p_b1 is not None and needs[1]) else None
     dx = _dgrad(dh, p_w1, w1)
+    if tp:
+        tp.all_reduce(dx)                                              # C4: entry gradient all-reduce
     return dx, (g_w1, g_b1, g_w2, g_b2)
 
 
@@ -155,47 +199,47 @@ class AttentionFn(torch.autograd.Function):
     """Attention.forward (building_blocks.py:157-192): qkv Linear -> fused SDPA -> proj Linear."""
 
     @staticmethod
-    def forward(ctx, x, qkvw, qkvb, projw, projb, num_heads, cdtype):
+    def forward(ctx, x, qkvw, qkvb, projw, projb, num_heads, cdtype, tp=None):
         xin = _as(x, cdtype)
         B, N, D = xin.shape
         x2 = xin.view(B * N, D)
         c = lambda p: compute_param(p, cdtype)
-        y, saved = _attn_fwd(x2, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), None)
+        y, saved = _attn_fwd(x2, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), None, tp)
         ctx.save_for_backward(x2, *saved, qkvw, qkvb, projw, projb)
-        ctx.meta = (B, N, num_heads, cdtype, x.dtype)
+        ctx.meta = (B, N, num_heads, cdtype, x.dtype, tp)
         return y.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dy):
         x2, qkv, o, lse, qkvw, qkvb, projw, projb = ctx.saved_tensors
-        B, N, H, cdtype, in_dtype = ctx.meta
+        B, N, H, cdtype, in_dtype, tp = ctx.meta
         dy2 = _as(dy, cdtype).reshape(x2.shape)
         c = lambda p: compute_param(p, cdtype)
-        dx, g = _attn_bwd(dy2, x2, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, ctx.needs_input_grad[1:5])
-        return (_ret_grad(dx.view(B, N, -1), in_dtype),) + g + (None, None)
+        dx, g = _attn_bwd(dy2, x2, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, ctx.needs_input_grad[1:5], tp)
+        return (_ret_grad(dx.view(B, N, -1), in_dtype),) + g + (None, None, None)
 
 
 class MlpFn(torch.autograd.Function):
     """Mlp.forward (building_blocks.py:122-129): fc1 -> erf-GELU -> fc2 (drops are p=0, norm=Identity)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, cdtype):
+    def forward(ctx, x, w1, b1, w2, b2, cdtype, tp=None):
         xin = _as(x, cdtype)
         x2 = xin.reshape(-1, xin.shape[-1])
         c = lambda p: compute_param(p, cdtype)
-        y, saved = _mlp_fwd(x2, c(w1), c(b1), c(w2), c(b2), None)
+        y, saved = _mlp_fwd(x2, c(w1), c(b1), c(w2), c(b2), None, tp)
         ctx.save_for_backward(x2, *saved, w1, b1, w2, b2)
-        ctx.meta = (cdtype, x.dtype, x.shape)
+        ctx.meta = (cdtype, x.dtype, x.shape, tp)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
     def backward(ctx, dy):
         x2, h, a, w1, b1, w2, b2 = ctx.saved_tensors
-        cdtype, in_dtype, in_shape = ctx.meta
+        cdtype, in_dtype, in_shape, tp = ctx.meta
         dy2 = _as(dy, cdtype).reshape(-1, dy.shape[-1])
         c = lambda p: compute_param(p, cdtype)
-        dx, g = _mlp_bwd(dy2, x2, (h, a), c(w1), c(w2), w1, b1, w2, b2, ctx.needs_input_grad[1:5])
-        return (_ret_grad(dx.view(in_shape), in_dtype),) + g + (None,)
+        dx, g = _mlp_bwd(dy2, x2, (h, a), c(w1), c(w2), w1, b1, w2, b2, ctx.needs_input_grad[1:5], tp)
+        return (_ret_grad(dx.view(in_shape), in_dtype),) + g + (None, None)
 
 
 class BlockFn(torch.autograd.Function):
@@ -204,33 +248,33 @@ class BlockFn(torch.autograd.Function):
     activation fused into GEMM epilogues; the residual-branch gradients are fused into the LayerNorm backward."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b, num_heads, eps, cdtype):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b, num_heads, eps, cdtype, tp=None):
         xin = _as(x, cdtype)
         B, N, D = xin.shape
         x2 = xin.view(B * N, D)
         c = lambda p: compute_param(p, cdtype)
         ln1, mean1, rstd1 = ops.layernorm_fwd(x2, c(n1w), c(n1b), eps)
-        x1, sa = _attn_fwd(ln1, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), x2)
+        x1, sa = _attn_fwd(ln1, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), x2, tp)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, c(n2w), c(n2b), eps)
-        y, sm = _mlp_fwd(ln2, c(f1w), c(f1b), c(f2w), c(f2b), x1)
+        y, sm = _mlp_fwd(ln2, c(f1w), c(f1b), c(f2w), c(f2b), x1, tp)
         ctx.save_for_backward(x2, mean1, rstd1, ln1, *sa, x1, mean2, rstd2, ln2, *sm,
                               n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b)
-        ctx.meta = (B, N, num_heads, cdtype, x.dtype)
+        ctx.meta = (B, N, num_heads, cdtype, x.dtype, tp)
         return y.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dy):
         (x2, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, h, a,
          n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b) = ctx.saved_tensors
-        B, N, H, cdtype, in_dtype = ctx.meta
+        B, N, H, cdtype, in_dtype, tp = ctx.meta
         need = ctx.needs_input_grad
         c = lambda p: compute_param(p, cdtype)
         dy2 = _as(dy, cdtype).reshape(x2.shape)
-        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13])
+        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp)
         dx1, g_n2w, g_n2b = _ln_bwd(dln2, x1, c(n2w), mean2, rstd2, n2w, n2b, dres=dy2)        # + residual branch
-        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7])
+        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7], tp)
         dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1)
-        return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None)
+        return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None)
 
 
 class PatchEmbedFn(torch.autograd.Function):
