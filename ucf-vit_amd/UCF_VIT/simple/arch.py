@@ -388,3 +388,164 @@ class MAE(VIT):
         """`noise` ([B, L] uniform) is an extension for reproducible masks / parity tests; None = torch.rand like the reference."""
         x, mask, ids_restore = self.forward_features(x, variables, seq_ps, noise)
         return self.forward_head(x, ids_restore, seq_ps), mask
+
+
+class UNETR(VIT):
+    """UNETR (reference :757-1113): ViT encoder on the HIP kernels with taps after blocks depth/4, 2*depth/4, 3*depth/4
+    (raw block outputs, forward_intermediates :995-1086), conv decoder on torch/MIOpen (unetr_blocks.py, parity unpinned).
+    forward(x, variables, seq_ps=None, x_seq=None) -> [B, num_classes, *img_size]"""
+
+    def __init__(self, *args, **kwargs):
+        self.linear_decoder = kwargs.pop('linear_decoder', '')
+        self.feature_size = kwargs.pop('feature_size', '')
+        self.skip_connection = kwargs.pop('skip_connection', '')
+        self.sqrt_len = kwargs.pop('sqrt_len', '')
+        super().__init__(*args, **kwargs)
+        self.head = None
+        from .unetr_blocks import UnetrBasicBlock, UnetrPrUpBlock, UnetrUpBlock, UnetOutBlock
+        nd = 2 if self.twoD else 3
+        if self.adaptive_patching:
+            self.feat_size = (self.sqrt_len,) * nd
+        else:
+            self.feat_size = tuple(int(self.img_size[i] / self.patch_size) for i in range(nd))
+        fs, D = self.feature_size, self.embed_dim
+        if not self.linear_decoder:
+            if self.skip_connection:
+                self.skip_indices = [(i + 1) * (self.depth // 4) for i in range(3)]
+                kw = dict(kernel_size=3, stride=1, upsample_kernel_size=2, norm_name="instance", conv_block=True, res_block=True)
+                self.encoder1 = UnetrBasicBlock(nd, self.in_chans, fs, kernel_size=3, stride=1, norm_name="instance", res_block=True)
+                self.encoder2 = UnetrPrUpBlock(nd, D, fs * 2, num_layer=2, **kw)
+                self.encoder3 = UnetrPrUpBlock(nd, D, fs * 4, num_layer=1, **kw)
+                self.encoder4 = UnetrPrUpBlock(nd, D, fs * 8, num_layer=0, **kw)
+                up = dict(kernel_size=3, upsample_kernel_size=2, norm_name="instance", res_block=True)
+                self.decoder5 = UnetrUpBlock(nd, D, fs * 8, **up)
+                self.decoder4 = UnetrUpBlock(nd, fs * 8, fs * 4, **up)
+                self.decoder3 = UnetrUpBlock(nd, fs * 4, fs * 2, **up)
+                full = self.feat_size[0] * 16 == self.img_size[0]
+                self.decoder2 = UnetrUpBlock(nd, fs * 2, fs, kernel_size=3, upsample_kernel_size=2 if full else 1, norm_name="instance", res_block=True)
+            else:
+                self.decoder5 = MyUnetBlock(nd, D, fs * 8, upsample_kernel_size=2, res_block=True)
+                self.decoder4 = MyUnetBlock(nd, fs * 8, fs * 4, upsample_kernel_size=2, res_block=True)
+                self.decoder3 = MyUnetBlock(nd, fs * 4, fs * 2, upsample_kernel_size=2, res_block=True)
+                self.decoder2 = MyUnetBlock(nd, fs * 2, fs, upsample_kernel_size=2, res_block=True)
+            self.out = UnetOutBlock(nd, fs, self.num_classes)
+            if self.feat_size[0] * 16 != self.img_size[0]:
+                self.upsample = nn.Upsample(size=self.img_size, mode='trilinear' if not self.twoD else 'bilinear', align_corners=True)
+        else:
+            self.mlp_head = Linear(D, self.num_classes)
+            self.upsample = nn.Upsample(scale_factor=self.patch_size, mode='trilinear' if not self.twoD else 'bilinear', align_corners=True)
+        self.init_weights('')
+
+    def proj_feat(self, x, hidden_size, feat_size):
+        x = x.float().view(x.size(0), *feat_size, hidden_size)
+        return x.permute(0, len(feat_size) + 1, *range(1, len(feat_size) + 1)).contiguous()
+
+    def forward_intermediates(self, x, variables, seq_ps, indices=None, return_prefix_tokens=False, norm=False, stop_early=False,
+                              intermediates_only=False):
+        take, max_index = feature_take_indices(len(self.blocks), indices)
+        self._prepare()
+        x = self._embed_tokens(x, variables)
+        x = self._pos_embed(x, seq_ps)
+        x = self.patch_drop(x)
+        intermediates = []
+        blocks = self.blocks if not stop_early else self.blocks[:max_index + 1]
+        for i, blk in enumerate(blocks):
+            x = blk(x)
+            if i in take:
+                intermediates.append(self.norm(x) if norm else x)
+        if self.num_prefix_tokens:
+            prefix = [y[:, 0:self.num_prefix_tokens] for y in intermediates]
+            intermediates = [y[:, self.num_prefix_tokens:] for y in intermediates]
+            if return_prefix_tokens:
+                intermediates = list(zip(intermediates, prefix))
+        if intermediates_only:
+            return intermediates
+        return self.norm(x), intermediates
+
+    def unetr_head(self, x, intermediates, enc1):
+        D, fz = self.embed_dim, self.feat_size
+        if not self.skip_connection:
+            if self.linear_decoder:
+                x = self.mlp_head(x).float()
+                x = x.view(x.size(0), *self.grid_size, -1).permute(0, len(fz) + 1, *range(1, len(fz) + 1))
+                return self.upsample(x)
+            out = self.decoder2(self.decoder3(self.decoder4(self.decoder5(self.proj_feat(x, D, fz)))))
+            if fz[0] * 16 != self.img_size[0]:
+                out = self.upsample(out)
+            return self.out(out)
+        n = len(intermediates)
+        dec4 = self.proj_feat(x, D, fz)
+        dec3 = self.decoder5(dec4, self.encoder4(self.proj_feat(intermediates[n - 1], D, fz)))
+        dec2 = self.decoder4(dec3, self.encoder3(self.proj_feat(intermediates[n - 2], D, fz)))
+        dec1 = self.decoder3(dec2, self.encoder2(self.proj_feat(intermediates[n - 3], D, fz)))
+        if fz[0] * 16 != self.img_size[0]:
+            dec1 = self.upsample(dec1)
+        return self.out(self.decoder2(dec1, enc1))
+
+    def forward_head(self, x, intermediates, enc1):
+        return self.unetr_head(self.pool(x), intermediates, enc1)
+
+    def forward(self, x, variables, seq_ps=None, x_seq=None):
+        tokens_in = x_seq if self.adaptive_patching else x
+        if self.skip_connection:
+            enc1 = self.encoder1(x)
+            feats, intermediates = self.forward_intermediates(tokens_in, variables, seq_ps, indices=self.skip_indices)
+            return self.forward_head(feats, intermediates, enc1)
+        return self.forward_head(self.forward_features(tokens_in, variables, seq_ps), None, None)
+
+
+class DiffusionVIT(VIT):
+    """Noise-prediction ViT (reference :1115-1283).  API surface and state_dict layout only: the reference's own forward path is
+    broken upstream (forward_features calls self._pos_embed(x) without seq_ps -> TypeError) and diffusion training
+    is out of scope.  forward(x, t, variables) here follows the evident intent: tokens + time embedding -> blocks."""
+
+    def __init__(self, *args, **kwargs):
+        self.linear_decoder = kwargs.pop('linear_decoder', '')
+        self.decoder_depth = kwargs.pop('decoder_depth', '')
+        self.decoder_embed_dim = kwargs.pop('decoder_embed_dim', '')
+        self.decoder_num_heads = kwargs.pop('decoder_num_heads', '')
+        self.mlp_ratio_decoder = kwargs.pop('mlp_ratio_decoder', '')
+        self.time_steps = kwargs.pop('time_steps', '')
+        super().__init__(*args, **kwargs)
+        self.head = None
+        self.temporalEmbeddings = SinusoidalEmbeddings(time_steps=self.time_steps, embed_dim=self.embed_dim)
+        self.timeEmbeddingMap = EmbeddingDenseLayer(self.embed_dim, self.embed_dim, 0.5)
+        dd = self.embed_dim if self.linear_decoder else self.decoder_embed_dim
+        self.decoder_pred = Linear(dd, self.patch_dim)
+        if not self.linear_decoder:
+            self.decoder_embed = Linear(self.embed_dim, dd)
+            self.decoder_norm = LayerNorm(dd)
+            if self.adaptive_patching:
+                self.decoder_pos_embed = nn.Parameter(torch.randn(1, self.num_patches, dd) * .02)
+            else:
+                self.decoder_pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, dd))
+            dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.decoder_depth)]
+            self.decoder_blocks = nn.Sequential(*[
+                self.block_fn(dim=dd, num_heads=self.decoder_num_heads, fused_attn=self.FusedAttn_option, mlp_ratio=self.mlp_ratio_decoder,
+                              qkv_bias=self.qkv_bias, qk_norm=self.qk_norm, init_values=self.init_values, proj_drop=self.proj_drop_rate,
+                              attn_drop=self.attn_drop_rate, drop_path=dpr[i], norm_layer=self.norm_layer, act_layer=self.act_layer,
+                              mlp_layer=self.mlp_layer) for i in range(self.decoder_depth)])
+        else:
+            self.decoder_pos_embed = None
+        self.init_weights('')
+
+    init_weights = MAE.init_weights
+
+    def forward_features(self, x, t, variables):
+        self._prepare()
+        x = self._embed_tokens(x, variables)
+        x = self._pos_embed(x, None)
+        time_emb = self.timeEmbeddingMap(self.temporalEmbeddings(x, t).float())[:, None, :]
+        x = x + time_emb.to(x.dtype)
+        return self.norm(self.blocks(x))
+
+    def forward_head(self, x):
+        x = self.pool(x)
+        if not self.linear_decoder:
+            x = self.decoder_embed(x)
+            x = x + self.decoder_pos_embed.to(x.dtype)
+            x = self.decoder_norm(self.decoder_blocks(x))
+        return self.decoder_pred(x)
+
+    def forward(self, x, t, variables):
+        return self.forward_head(self.forward_features(x, t.to('cpu'), variables))

@@ -1,0 +1,89 @@
+"""UNETR convolutional decoder blocks (3x3(x3) conv + instance norm + LeakyReLU residual blocks, transposed-conv upsampling,
+1x1 output conv).  In the reference these come from the un-vendored dependency monai>=1.4.0 (UnetrBasicBlock, UnetrPrUpBlock,
+UnetrUpBlock, UnetOutBlock; src/UCF_VIT/simple/arch.py:33-34,808-940): the classes below restate that published block
+structure and its state_dict naming so checkpoints line up.  PARITY UNPINNED: monai is not installed in the build container
+and the reference ships no fixtures for it.  The arithmetic stays on torch/MIOpen — the conv decoder is outside
+the round-1 HIP hot path; only the transformer encoder of UNETR runs on libucfvit_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+
+def _conv(nd, cin, cout, k, s, transposed=False, bias=False):
+    cls = {(2, False): nn.Conv2d, (3, False): nn.Conv3d, (2, True): nn.ConvTranspose2d, (3, True): nn.ConvTranspose3d}[(nd, transposed)]
+    pad = 0 if transposed else (k - s + 1) // 2
+    m = nn.Sequential()
+    m.add_module("conv", cls(cin, cout, kernel_size=k, stride=s, padding=pad, bias=bias))   # key '<name>.conv.weight' like monai's Convolution
+    return m
+
+
+def _inorm(nd, c):
+    return (nn.InstanceNorm2d if nd == 2 else nn.InstanceNorm3d)(c)
+
+
+class UnetResBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name="instance"):
+        super().__init__()
+        nd = spatial_dims
+        self.conv1 = _conv(nd, in_channels, out_channels, kernel_size, stride)
+        self.conv2 = _conv(nd, out_channels, out_channels, kernel_size, 1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.01, inplace=True)
+        self.norm1, self.norm2 = _inorm(nd, out_channels), _inorm(nd, out_channels)
+        self.downsample = in_channels != out_channels or stride != 1
+        if self.downsample:
+            self.conv3 = _conv(nd, in_channels, out_channels, 1, stride)
+            self.norm3 = _inorm(nd, out_channels)
+
+    def forward(self, inp):
+        out = self.lrelu(self.norm1(self.conv1(inp)))
+        out = self.norm2(self.conv2(out))
+        residual = self.norm3(self.conv3(inp)) if self.downsample else inp
+        return self.lrelu(out + residual)
+
+
+class UnetrBasicBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, res_block=False):
+        super().__init__()
+        self.layer = UnetResBlock(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name)
+
+    def forward(self, inp):
+        return self.layer(inp.float())
+
+
+class UnetrPrUpBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, num_layer, kernel_size, stride, upsample_kernel_size, norm_name,
+                 conv_block=False, res_block=False):
+        super().__init__()
+        u = upsample_kernel_size
+        self.transp_conv_init = _conv(spatial_dims, in_channels, out_channels, u, u, transposed=True)
+        self.blocks = nn.ModuleList([
+            nn.Sequential(_conv(spatial_dims, out_channels, out_channels, u, u, transposed=True),
+                          UnetResBlock(spatial_dims, out_channels, out_channels, kernel_size, stride, norm_name))
+            for _ in range(num_layer)])
+
+    def forward(self, x):
+        x = self.transp_conv_init(x.float())
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+class UnetrUpBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, upsample_kernel_size, norm_name, res_block=False):
+        super().__init__()
+        u = upsample_kernel_size
+        self.transp_conv = _conv(spatial_dims, in_channels, out_channels, u, u, transposed=True)
+        self.conv_block = UnetResBlock(spatial_dims, out_channels + out_channels, out_channels, kernel_size, 1, norm_name)
+
+    def forward(self, inp, skip):
+        out = self.transp_conv(inp.float())
+        return self.conv_block(torch.cat((out, skip), dim=1))
+
+
+class UnetOutBlock(nn.Module):
+    def __init__(self, spatial_dims, in_channels, out_channels):
+        super().__init__()
+        self.conv = _conv(spatial_dims, in_channels, out_channels, 1, 1, bias=True)
+
+    def forward(self, inp):
+        return self.conv(inp)

@@ -1,0 +1,108 @@
+"""Shared plumbing of the train_*_simple.py entry points (reference: training_scripts/train_class_simple.py:33-446 and siblings):
+YAML config in the reference schema, one process per GPU over RCCL, even/odd checkpoints with the reference's dictionary
+layout, and a synthetic data source (the reference dataloaders are out of scope: SURVEY.md §2)."""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+
+def init_distributed(launcher=None):
+    """rank / world from torchrun env, SLURM env (reference :426-437) or a single process; backend nccl (= RCCL)"""
+    env = os.environ
+    if "RANK" in env:
+        rank, world, local = int(env["RANK"]), int(env["WORLD_SIZE"]), int(env.get("LOCAL_RANK", 0))
+    elif "SLURM_PROCID" in env:
+        rank, world = int(env["SLURM_PROCID"]), int(env["SLURM_NTASKS"])
+        local = int(env.get("SLURM_LOCALID", rank % max(1, torch.cuda.device_count())))
+    else:
+        rank, world, local = 0, 1, 0
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return device, local, rank, world
+
+
+def load_config(path):
+    with open(path) as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def model_args(conf):
+    """the subset of `model.net.init_args` + `data` the hot-path models use"""
+    a, d = conf["model"]["net"]["init_args"], conf["data"]
+    dataset = d["dataset"]
+    chans = 1 if d.get("single_channel", False) else max(1, d["num_channels_used"][dataset])
+    if a.get("adaptive_patching", False) or a.get("use_varemb", False):
+        raise NotImplementedError("adaptive_patching / use_varemb configs are 'next' rows (SURVEY.md §8f); set them False")
+    return dict(img_size=a["tile_size"], patch_size=a["patch_size"], in_chans=chans, embed_dim=a["embed_dim"], depth=a["depth"],
+                num_heads=a["num_heads"], mlp_ratio=a["mlp_ratio"], drop_path_rate=a.get("drop_path", 0.0), twoD=a["twoD"],
+                default_vars=a["default_vars"], single_channel=d.get("single_channel", False), use_varemb=False,
+                adaptive_patching=False, fixed_length=a.get("fixed_length", 4096)), a, d
+
+
+class SyntheticLoader:
+    """per-rank synthetic batches shaped like the reference dataloader's output: (data fp32 un-normalised, label, variables)"""
+
+    def __init__(self, batch_size, in_chans, img_size, num_classes, iters, device, seed, volumetric_labels=False):
+        self.shape = (batch_size, in_chans, *img_size)
+        self.num_classes, self.iters, self.device, self.seed = num_classes, iters, device, seed
+        self.volumetric_labels = volumetric_labels
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for _ in range(self.iters):
+            data = torch.randint(0, 256, self.shape, generator=g).float()
+            if self.volumetric_labels:
+                label = torch.randint(0, self.num_classes, (self.shape[0], 1, *self.shape[2:]), generator=g)
+            else:
+                label = torch.randint(0, max(self.num_classes, 1), (self.shape[0],), generator=g)
+            yield data.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
+
+
+def save_checkpoint(conf, epoch, model, optimizer, scheduler, loss_list, rank):
+    """alternating <name>_even.ckpt / _odd.ckpt on rank 0 (reference :364-388), same dictionary keys"""
+    t = conf["trainer"]
+    if rank == 0:
+        os.makedirs(t["checkpoint_path"], exist_ok=True)
+        torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                    "scheduler_state_dict": scheduler.state_dict(), "loss_list": loss_list},
+                   os.path.join(t["checkpoint_path"], f"{t['checkpoint_filename']}_{'even' if epoch % 2 == 0 else 'odd'}.ckpt"))
+    dist.barrier()
+
+
+def maybe_resume(conf, model, optimizer, scheduler):
+    t = conf["trainer"]
+    if not t.get("resume_from_checkpoint", False):
+        return 0, []
+    ck = torch.load(os.path.join(t["checkpoint_path"], t["checkpoint_filename_for_loading"] + ".ckpt"), map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["model_state_dict"])
+    optimizer.load_state_dict(ck["optimizer_state_dict"])
+    scheduler.load_state_dict(ck["scheduler_state_dict"])
+    return ck["epoch"] + 1, ck["loss_list"]
+
+
+def iters_per_epoch(conf):
+    return max(conf["load_balancing"]["batches_per_rank_epoch"].values())
+
+
+class StepTimer:
+    def __init__(self):
+        self.t0, self.n = time.perf_counter(), 0
+
+    def tick(self, imgs):
+        self.n += imgs
+
+    def rate(self):
+        torch.cuda.synchronize()
+        return self.n / (time.perf_counter() - self.t0)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""UNETR segmentation training — entry point compatible with the reference's training_scripts/train_unetr_simple.py.
+The ViT encoder runs on the HIP kernels; the conv decoder and the Dice+CE loss (monai DiceCELoss(to_onehot_y, softmax,
+squared_pred) in the reference, :38) are restated with torch ops (parity unpinned: monai is not vendored)."""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+from _common import (SyntheticLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
+                     save_checkpoint)
+from UCF_VIT.simple.arch import UNETR
+from UCF_VIT.utils.fused_attn import FusedAttn
+from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
+from UCF_VIT._hip.ddp import HipDataParallel
+
+
+def dice_ce_loss(logits, label, smooth=1e-5):
+    """DiceLoss(softmax, one-hot target, squared_pred, mean over batch and classes) + CrossEntropy"""
+    n = logits.shape[1]
+    prob = logits.float().softmax(dim=1)
+    onehot = F.one_hot(label.squeeze(1), n).movedim(-1, 1).float()
+    dims = tuple(range(2, logits.dim()))
+    inter = (prob * onehot).sum(dims)
+    denom = (prob ** 2).sum(dims) + (onehot ** 2).sum(dims)
+    dice = 1.0 - (2.0 * inter + smooth) / (denom + smooth)
+    return dice.mean() + F.cross_entropy(logits.float(), label.squeeze(1))
+
+
+def training_step(data, variables, label, net):
+    output = net(data, variables, None, None)
+    return dice_ce_loss(output, label), output
+
+
+def main(device, local_rank, rank, world):
+    conf = load_config(sys.argv[1])
+    margs, a, d = model_args(conf)
+    m = conf["model"]
+    model = UNETR(num_classes=d["num_classes"], class_token=False, weight_init='', linear_decoder=a.get("linear_decoder", False),
+                  feature_size=a.get("feature_size", 16), skip_connection=a.get("skip_connection", True),
+                  FusedAttn_option=FusedAttn.HIP, **margs).to(device)
+    model.set_compute_dtype(torch.bfloat16 if conf["trainer"].get("data_type", "float32") == "bfloat16" else torch.float32)
+    net = HipDataParallel(model)
+    optimizer = configure_optimizer(model, m["lr"], m["beta_1"], m["beta_2"], m["weight_decay"])
+    scheduler = configure_scheduler(optimizer, m["warmup_steps"], m["max_steps"], m["warmup_start_lr"], m["eta_min"])
+    epoch_start, loss_list = maybe_resume(conf, net, optimizer, scheduler)
+    variables = d["dict_in_variables"][d["dataset"]]
+    loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], d["num_classes"], iters_per_epoch(conf), device,
+                             1234 + rank, volumetric_labels=True)
+    for epoch in range(epoch_start, conf["trainer"]["max_epochs"]):
+        model.train()
+        epoch_loss = torch.zeros((), device=device)
+        timer = StepTimer()
+        for data, label in loader:
+            loss, _ = training_step(data / 255.0, variables, label, net)       # basic_ct volumes are min-max normalised
+            epoch_loss += loss.detach()
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            scheduler.step()
+            timer.tick(data.shape[0] * world)
+        loss_list.append(epoch_loss)
+        if rank == 0:
+            print(f"epoch: {epoch} epoch_loss {epoch_loss.item():.4f} volumes/s {timer.rate():.2f}", flush=True)
+        save_checkpoint(conf, epoch, net, optimizer, scheduler, loss_list, rank)
+
+
+if __name__ == "__main__":
+    dev, lr_, r, w = init_distributed(sys.argv[2] if len(sys.argv) > 2 else None)
+    main(dev, lr_, r, w)
+    torch.distributed.destroy_process_group()
