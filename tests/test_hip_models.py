@@ -223,3 +223,24 @@ def test_sap_and_diffusion_api_surface():
                      decoder_depth=1, decoder_embed_dim=32, decoder_num_heads=1, mlp_ratio_decoder=4.0, time_steps=10).to(DEV).eval()
     out = d(det_tensor((2, 3, 32, 32), 2).to(DEV), torch.tensor([1, 7]), None)
     assert tuple(out.shape) == (2, 16, 192)
+
+
+def test_train_class_simple_entry_point_runs(tmp_path):
+    """BASELINE.json configs[0] plumbing: the reference-compatible entry script runs 2 epochs of ViT-Tiny/16 (catsdogs shape,
+    batch 8, synthetic data) on one GPU through RCCL world_size 1 and writes the even/odd checkpoints"""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from conftest import ROOT
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "ucf-vit_amd", "configs", "catsdogs_vit_tiny_smoke.yaml")))
+    cfg["trainer"]["checkpoint_path"] = str(tmp_path)
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    env = dict(os.environ, MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "ucf-vit_amd", "training_scripts", "train_class_simple.py"), str(p)],
+                         capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "epoch: 1" in out.stdout
+    ck = torch.load(tmp_path / "multi_last_odd.ckpt", map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 1 and "module.blocks.11.mlp.fc2.weight" in ck["model_state_dict"]
