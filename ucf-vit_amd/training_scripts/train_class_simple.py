@@ -27,8 +27,8 @@ def main(device, local_rank, rank, world):
     model = VIT(num_classes=d["num_classes"], drop_rate=a.get("drop_rate", 0.0), weight_init='', FusedAttn_option=FusedAttn.HIP, **margs).to(device)
     model.set_compute_dtype(torch.bfloat16 if conf["trainer"].get("data_type", "float32") == "bfloat16" else torch.float32)
     net = HipDataParallel(model)                                             # reference: DDP(model, find_unused_parameters=True)
-    optimizer = configure_optimizer(model, m["lr"], m["beta_1"], m["beta_2"], m["weight_decay"])
-    scheduler = configure_scheduler(optimizer, m["warmup_steps"], m["max_steps"], m["warmup_start_lr"], m["eta_min"])
+    optimizer = configure_optimizer(model, float(m["lr"]), float(m["beta_1"]), float(m["beta_2"]), float(m["weight_decay"]))   # PyYAML reads "1e-5" as str
+    scheduler = configure_scheduler(optimizer, int(m["warmup_steps"]), int(m["max_steps"]), float(m["warmup_start_lr"]), float(m["eta_min"]))
     epoch_start, loss_list = maybe_resume(conf, net, optimizer, scheduler)
     variables = d["dict_in_variables"][d["dataset"]]
     loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], d["num_classes"], iters_per_epoch(conf), device, 1234 + rank)

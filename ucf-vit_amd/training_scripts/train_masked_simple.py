@@ -29,8 +29,8 @@ def main(device, local_rank, rank, world):
                 mlp_ratio_decoder=a["mlp_ratio_decoder"], FusedAttn_option=FusedAttn.HIP, **margs).to(device)
     model.set_compute_dtype(torch.bfloat16 if conf["trainer"].get("data_type", "float32") == "bfloat16" else torch.float32)
     net = HipDataParallel(model)
-    optimizer = configure_optimizer(model, m["lr"], m["beta_1"], m["beta_2"], m["weight_decay"])
-    scheduler = configure_scheduler(optimizer, m["warmup_steps"], m["max_steps"], m["warmup_start_lr"], m["eta_min"])
+    optimizer = configure_optimizer(model, float(m["lr"]), float(m["beta_1"]), float(m["beta_2"]), float(m["weight_decay"]))   # PyYAML reads "1e-5" as str
+    scheduler = configure_scheduler(optimizer, int(m["warmup_steps"]), int(m["max_steps"]), float(m["warmup_start_lr"]), float(m["eta_min"]))
     epoch_start, loss_list = maybe_resume(conf, net, optimizer, scheduler)
     variables = d["dict_in_variables"][d["dataset"]]
     loss_fn = conf["trainer"].get("loss_fn", a.get("loss_fn", "MSE"))
