@@ -243,7 +243,7 @@ def test_cpu_tensor_is_rejected_loudly():
 
 
 # ---------------------------------------------------------------------------------------------- large-tile bf16 GEMM (v2 kernel)
-@pytest.mark.parametrize("M,N,K", [(3428, 4096, 128), (1000, 512, 256), (2500, 264, 192)])
+@pytest.mark.parametrize("M,N,K", [(3428, 4096, 128), (1000, 512, 256), (2500, 264, 192), (3400, 4096, 200), (700, 384, 136)])
 def test_gemm_v2_tiles_edges_epilogues(M, N, K):
     """256x256 (first shape) and 128x128 tile configs, ragged M/N edges, every operand layout and epilogue, vs fp64"""
     from UCF_VIT._hip import ops
@@ -274,7 +274,7 @@ def test_gemm_v2_tiles_edges_epilogues(M, N, K):
     assert rel_err(dx.float(), (dy64 @ W64) * aux64.grad) < 1e-2
 
 
-@pytest.mark.parametrize("Mtok,N,K", [(25216 // 8, 1024, 1024), (3200, 256, 384), (6400, 3072, 128)])
+@pytest.mark.parametrize("Mtok,N,K", [(25216 // 8, 1024, 1024), (3200, 256, 384), (6400, 3072, 128), (3208, 512, 256), (4136, 1024, 4096), (3302, 1024, 512)])
 def test_gemm_v2_wgrad_splitk(Mtok, N, K):
     """weight gradient (KS x KS) with split-K partial sums: fp32 output, overwrite then accumulate"""
     from UCF_VIT._hip import ops

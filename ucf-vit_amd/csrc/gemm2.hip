@@ -9,7 +9,7 @@
 //               [k][rows] read by ds_read_b64_tr_b16 (hardware transpose) — weight-gradient and data-gradient GEMMs need
 //               no transposed copies of activations or weights in HBM.
 //   edges     : rows/cols beyond M/N are CLAMPED on load (duplicates of valid data) and masked in the epilogue;
-//               the contraction extent must be a multiple of 64 (host-checked, else gemm.hip's v1 kernel runs).
+//               a ragged last K-tile (K % 64 != 0, K % 8 == 0) is zero-filled by pointing the out-of-range DMA lanes at a zero page.
 //   split-K   : gridDim.y K-slices write fp32 partial matrices to a caller workspace; a second kernel sums them in a fixed
 //               order (deterministic) and applies accumulate.  Used when the output has too few tiles to fill 256 CUs.
 #include <stdlib.h>
@@ -29,9 +29,14 @@ __device__ __forceinline__ int ks_off2(int krow, int colbyte) { return krow * (B
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Source of the zero fill for the ragged last K-tile: lanes whose contraction index is >= K read this page instead of the
+// operand (a DMA lane cannot be predicated off without leaving stale LDS bytes).
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[1024];
+
 // Issue the DMA loads of one operand K-tile.  Every wave issues NPW wave-instructions of 1 KiB.
 template <int LAYOUT, int BR, int NWAVES>
-__device__ __forceinline__ void issue_tile(const bf16* __restrict__ base, int64_t ld, int r0, int k0, int R, char* lds, int wave, int lane) {
+__device__ __forceinline__ void issue_tile(const bf16* __restrict__ base, int64_t ld, int r0, int k0, int R, char* lds, int wave, int lane,
+                                           int krem = BK2) {
     constexpr int NPIECES = BR / 8;  // 1-KiB pieces per K-tile (tile bytes = BR * 128)
     constexpr int NPW = NPIECES / NWAVES;
 #pragma unroll
@@ -44,6 +49,7 @@ __device__ __forceinline__ void issue_tile(const bf16* __restrict__ base, int64_
             int gr = r0 + row;
             gr = gr < R ? gr : R - 1;
             src = base + (int64_t)gr * ld + k0 + gslot * 8;
+            if (gslot * 8 >= krem) src = reinterpret_cast<const bf16*>(g_zero_page) + lane * 8;
         } else {
             constexpr int RB = BR * 2;          // bytes per k-row
             constexpr int KPP = 1024 / RB;      // k-rows per piece
@@ -53,6 +59,7 @@ __device__ __forceinline__ void issue_tile(const bf16* __restrict__ base, int64_
             int gc = r0 + col;
             gc = gc <= R - 8 ? gc : R - 8;
             src = base + (int64_t)(k0 + krow) * ld + gc;
+            if (krow >= krem) src = reinterpret_cast<const bf16*>(g_zero_page) + lane * 8;
         }
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + idx * 1024), 16, 0, 0);
     }
@@ -119,7 +126,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
 
     const int k_begin = blockIdx.y * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
-    const int nk = (k_end - k_begin) / BK2;
+    const int nk = (k_end - k_begin + BK2 - 1) / BK2;
+    const int klast = k_end - k_begin - (nk - 1) * BK2;      // valid contraction extent of the last K-tile (1..64)
     float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
 
     // epilogue staging geometry (wave-private LDS rows inside the just-consumed pipeline buffer)
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
         if ((int)blockIdx.x >= first) return;
         tile_origin(xcd_remap(blockIdx.x, first), tiles_m, tiles_n, BM, BN, m0, n0);
     }
-    issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin, M, smem, wave, lane);
-    issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin, N, smem + A_BYTES, wave, lane);
+    issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin, M, smem, wave, lane, nk == 1 ? klast : BK2);
+    issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin, N, smem + A_BYTES, wave, lane, nk == 1 ? klast : BK2);
 
     for (int round = 0;; ++round) {
         // next tile of this workgroup (if any)
@@ -161,11 +169,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
             const char* bufB = bufA + A_BYTES;
             char* nb = smem + ((it + 1) & 1) * BUF;
             if (kt + 1 < nk) {
-                issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin + (kt + 1) * BK2, M, nb, wave, lane);
-                issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin + (kt + 1) * BK2, N, nb + A_BYTES, wave, lane);
+                const int kr = (kt + 2 == nk) ? klast : BK2;
+                issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin + (kt + 1) * BK2, M, nb, wave, lane, kr);
+                issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin + (kt + 1) * BK2, N, nb + A_BYTES, wave, lane, kr);
             } else if (has_next) {
-                issue_tile<LA, BM, NWAVES>(A, lda, nm0, k_begin, M, nb, wave, lane);
-                issue_tile<LB, BN, NWAVES>(B, ldb, nn0, k_begin, N, nb + A_BYTES, wave, lane);
+                const int kr = nk == 1 ? klast : BK2;
+                issue_tile<LA, BM, NWAVES>(A, lda, nm0, k_begin, M, nb, wave, lane, kr);
+                issue_tile<LB, BN, NWAVES>(B, ldb, nn0, k_begin, N, nb + A_BYTES, wave, lane, kr);
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -336,6 +346,26 @@ __device__ __forceinline__ void issue_half(const char* __restrict__ base_k, cons
         __builtin_amdgcn_global_load_lds((gptr_t)(base_k + off[i]), (lptr_t)(lds + idx * 1024), 16, 0, 0);
     }
 }
+// ragged last K-tile: lanes beyond the valid contraction extent `krem` read the zero page
+template <int LAYOUT, int BR>
+__device__ __forceinline__ void issue_half_tail(const char* __restrict__ base_k, const unsigned (&off)[4], char* lds, int grp, int w4, int lane,
+                                                int krem) {
+    constexpr int NP = BR / 8, PER = NP / 8;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = grp * (NP / 2) + w4 * PER + i;
+        bool ok;
+        if (LAYOUT == UCFVIT_LAYOUT_KC) {
+            const int row = idx * 8 + (lane >> 3);
+            ok = (((lane & 7) ^ (row & 7)) * 8) < krem;
+        } else {
+            constexpr int RB = BR * 2, KPP = 1024 / RB;
+            ok = (idx * KPP + (lane * 16) / RB) < krem;
+        }
+        const char* src = ok ? base_k + off[i] : reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + idx * 1024), 16, 0, 0);
+    }
+}
 // wave-uniform byte offset of K position k0 for an operand
 template <int LAYOUT> __device__ __forceinline__ int64_t k_byte_off(int k0, int64_t ld) {
     return LAYOUT == UCFVIT_LAYOUT_KC ? (int64_t)k0 * 2 : (int64_t)k0 * ld * 2;
@@ -373,7 +403,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
 
     const int k_begin = blockIdx.y * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
-    const int nk = (k_end - k_begin) / BK2;
+    const int nk = (k_end - k_begin + BK2 - 1) / BK2;
+    const int klast = k_end - k_begin - (nk - 1) * BK2;      // valid contraction extent of the last K-tile (1..64)
     float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
 
     constexpr int PADW = TN + 4, LPR = TN / 8, RPI = 64 / LPR;
@@ -392,8 +423,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
     unsigned offA[4], offB[4];
     half_offsets<LA, BM>(offA, lda, m0, M, grp, w4, lane);
     half_offsets<LB, BN>(offB, ldb, n0, N, grp, w4, lane);
-    issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, smem, grp, w4);
-    issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, smem + A_BYTES, grp, w4);
+    if (nk == 1 && klast < BK2) {
+        issue_half_tail<LA, BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, smem, grp, w4, lane, klast);
+        issue_half_tail<LB, BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, smem + A_BYTES, grp, w4, lane, klast);
+    } else {
+        issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, smem, grp, w4);
+        issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, smem + A_BYTES, grp, w4);
+    }
     PP_WAIT_DMA();
     PP_BARRIER();
 
@@ -429,13 +465,23 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
     do {                                                                                       \
         char* nb = smem + ((it + 1) & 1) * BUF;                                                \
         if ((kt_) + 1 < nk) {                                                                  \
-            issue_half<BM>(Ab + k_byte_off<LA>(k_begin + ((kt_) + 1) * BK2, lda), offA, nb, grp, w4);            \
-            issue_half<BN>(Bb + k_byte_off<LB>(k_begin + ((kt_) + 1) * BK2, ldb), offB, nb + A_BYTES, grp, w4);  \
+            if ((kt_) + 2 == nk && klast < BK2) {                                              \
+                issue_half_tail<LA, BM>(Ab + k_byte_off<LA>(k_begin + ((kt_) + 1) * BK2, lda), offA, nb, grp, w4, lane, klast);           \
+                issue_half_tail<LB, BN>(Bb + k_byte_off<LB>(k_begin + ((kt_) + 1) * BK2, ldb), offB, nb + A_BYTES, grp, w4, lane, klast); \
+            } else {                                                                           \
+                issue_half<BM>(Ab + k_byte_off<LA>(k_begin + ((kt_) + 1) * BK2, lda), offA, nb, grp, w4);            \
+                issue_half<BN>(Bb + k_byte_off<LB>(k_begin + ((kt_) + 1) * BK2, ldb), offB, nb + A_BYTES, grp, w4);  \
+            }                                                                                  \
         } else if (has_next) {                                                                 \
             half_offsets<LA, BM>(offA, lda, nm0, M, grp, w4, lane);  /* offsets now belong to the next tile */ \
             half_offsets<LB, BN>(offB, ldb, nn0, N, grp, w4, lane);                            \
-            issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, nb, grp, w4);              \
-            issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, nb + A_BYTES, grp, w4);    \
+            if (nk == 1 && klast < BK2) {                                                      \
+                issue_half_tail<LA, BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, nb, grp, w4, lane, klast);           \
+                issue_half_tail<LB, BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, nb + A_BYTES, grp, w4, lane, klast); \
+            } else {                                                                           \
+                issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, nb, grp, w4);          \
+                issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, nb + A_BYTES, grp, w4);\
+            }                                                                                  \
         }                                                                                      \
     } while (0)
 
@@ -596,10 +642,13 @@ struct Plan2 {
 
 inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
     if (d->dtype != UCFVIT_BF16) return false;
-    if (d->K < 128 || d->K % BK2 != 0) return false;
+    if (d->K < 128) return false;
+    // ragged last K-tile is zero-filled by the DMA issue; 16-byte vectors along K need K % 8 == 0 only for KC operands
+    if ((d->a_layout == UCFVIT_LAYOUT_KC || d->b_layout == UCFVIT_LAYOUT_KC) && d->K % 8 != 0) return false;
     if (d->M < 128 || d->N < 128) return false;
     const int64_t t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     const int64_t t128 = ((d->M + 127) / 128) * ((d->N + 127) / 128);
+    const int64_t ktiles_all = (d->K + BK2 - 1) / BK2;
     const bool plain_epi = !d->bias && !d->residual && !d->aux_in && !d->aux_out && d->act == UCFVIT_ACT_NONE;
     p->splits = 1;
     static int force_small = -1;
@@ -613,14 +662,14 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
         p->big = 0;
         if (plain_epi && t128 < 384) {
             int s = (int)((512 + t128 - 1) / t128);          // aim at ~512 workgroups (2 per CU)
-            const int kmax = (int)(d->K / (8 * BK2));        // at least 8 K-tiles per slice
+            const int kmax = (int)(ktiles_all / 8);          // at least 8 K-tiles per slice
             if (s > kmax) s = kmax;
             if (s > 16) s = 16;
             if (s < 1) s = 1;
             p->splits = s;
         }
     }
-    const int64_t ktiles = d->K / BK2;
+    const int64_t ktiles = (d->K + BK2 - 1) / BK2;
     p->k_per_split = (int)(((ktiles + p->splits - 1) / p->splits) * BK2);
     p->splits = (int)((d->K + p->k_per_split - 1) / p->k_per_split);
     return true;
