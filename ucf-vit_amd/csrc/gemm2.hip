@@ -379,6 +379,12 @@ template <int LAYOUT> __device__ __forceinline__ int64_t k_byte_off(int k0, int6
         asm volatile("" ::: "memory");            \
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
+#define PP_WAIT_B() /* all but the 4 youngest (the A pieces just issued) */ \
+    do {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
 #define PP_WAIT_DMA()                                      \
     do {                                                   \
         __builtin_amdgcn_sched_barrier(0);                 \
@@ -461,29 +467,24 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                         \
     } while (0)
-#define PP_ISSUE_NEXT(kt_)                                                                     \
+#define PP_ISSUE_ONE(LAY_, BR_, base_, ld_, off_, r0n_, Rn_, ldsoff_, kt_)                       \
     do {                                                                                       \
-        char* nb = smem + ((it + 1) & 1) * BUF;                                                \
+        char* nb = smem + ((it + 1) & 1) * BUF + (ldsoff_);                                    \
         if ((kt_) + 1 < nk) {                                                                  \
-            if ((kt_) + 2 == nk && klast < BK2) {                                              \
-                issue_half_tail<LA, BM>(Ab + k_byte_off<LA>(k_begin + ((kt_) + 1) * BK2, lda), offA, nb, grp, w4, lane, klast);           \
-                issue_half_tail<LB, BN>(Bb + k_byte_off<LB>(k_begin + ((kt_) + 1) * BK2, ldb), offB, nb + A_BYTES, grp, w4, lane, klast); \
-            } else {                                                                           \
-                issue_half<BM>(Ab + k_byte_off<LA>(k_begin + ((kt_) + 1) * BK2, lda), offA, nb, grp, w4);            \
-                issue_half<BN>(Bb + k_byte_off<LB>(k_begin + ((kt_) + 1) * BK2, ldb), offB, nb + A_BYTES, grp, w4);  \
-            }                                                                                  \
+            if ((kt_) + 2 == nk && klast < BK2)                                                \
+                issue_half_tail<LAY_, BR_>(base_ + k_byte_off<LAY_>(k_begin + ((kt_) + 1) * BK2, ld_), off_, nb, grp, w4, lane, klast); \
+            else                                                                               \
+                issue_half<BR_>(base_ + k_byte_off<LAY_>(k_begin + ((kt_) + 1) * BK2, ld_), off_, nb, grp, w4); \
         } else if (has_next) {                                                                 \
-            half_offsets<LA, BM>(offA, lda, nm0, M, grp, w4, lane);  /* offsets now belong to the next tile */ \
-            half_offsets<LB, BN>(offB, ldb, nn0, N, grp, w4, lane);                            \
-            if (nk == 1 && klast < BK2) {                                                      \
-                issue_half_tail<LA, BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, nb, grp, w4, lane, klast);           \
-                issue_half_tail<LB, BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, nb + A_BYTES, grp, w4, lane, klast); \
-            } else {                                                                           \
-                issue_half<BM>(Ab + k_byte_off<LA>(k_begin, lda), offA, nb, grp, w4);          \
-                issue_half<BN>(Bb + k_byte_off<LB>(k_begin, ldb), offB, nb + A_BYTES, grp, w4);\
-            }                                                                                  \
+            half_offsets<LAY_, BR_>(off_, ld_, r0n_, Rn_, grp, w4, lane);  /* offsets now belong to the next tile */ \
+            if (nk == 1 && klast < BK2)                                                        \
+                issue_half_tail<LAY_, BR_>(base_ + k_byte_off<LAY_>(k_begin, ld_), off_, nb, grp, w4, lane, klast); \
+            else                                                                               \
+                issue_half<BR_>(base_ + k_byte_off<LAY_>(k_begin, ld_), off_, nb, grp, w4);    \
         }                                                                                      \
     } while (0)
+#define PP_ISSUE_B(kt_) PP_ISSUE_ONE(LB, BN, Bb, ldb, offB, nn0, N, A_BYTES, kt_)
+#define PP_ISSUE_A(kt_) PP_ISSUE_ONE(LA, BM, Ab, lda, offA, nm0, M, 0, kt_)
 
         // One program for both groups; G1 runs it one barrier interval behind G0 (extra barrier before / after the loop).
         if (grp == 1) PP_BARRIER();
@@ -491,22 +492,25 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
         for (int kt = 0; kt < nk; ++kt, ++it) {
             const char* bufA = smem + (it & 1) * BUF;
             const char* bufB = bufA + A_BYTES;
-            PP_ISSUE_NEXT(kt);              // MEM(c0): DMA of this group's half of the next K-tile + fragment reads
+            PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) + fragment reads
             PP_READ(bufA, bufB, 0);
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c0)
             PP_BARRIER();
-            PP_READ(bufA, bufB, 1);         // MEM(c1)
-            if (grp == 1) PP_WAIT_DMA();    // G1's DMA (issued 2 intervals ago) must be visible before G0's next MEM(c0)
+            PP_ISSUE_A(kt);                 // MEM(c1): DMA of this group's OWN rows of the next A tile (first read by itself, 2 intervals on)
+            PP_READ(bufA, bufB, 1);
+            if (grp == 1) PP_WAIT_B();      // G1's B half (issued 2 intervals ago) must be visible before G0's next MEM(c0); its A pieces stay in flight
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c1)
-            if (grp == 0) PP_WAIT_DMA();    // G0's DMA was issued 3 intervals ago
+            PP_WAIT_DMA();                  // everything this wave issued for the next K-tile has landed
             PP_BARRIER();
         }
         if (grp == 0) PP_BARRIER();
 #undef PP_READ
 #undef PP_COMPUTE
-#undef PP_ISSUE_NEXT
+#undef PP_ISSUE_ONE
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
 
         // ---- epilogue (same as gemm2_kernel): staging area = the pipeline buffer of the K-tile just consumed ----------
         __builtin_amdgcn_sched_barrier(0);
