@@ -91,6 +91,11 @@ typedef struct ucfvit_gemm_desc {
 int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* desc);
 int ucfvit_gemm(const ucfvit_gemm_desc* desc, void* stream);
 
+/* n <= 4 epilogue-free GEMMs with the same K, layouts and dtypes (the four weight gradients of a transformer Block:
+ * dW_qkv, dW_proj, dW_fc1, dW_fc2 all contract over the B*N tokens) as ONE persistent launch over the union of their output
+ * tiles: fills the 256 CUs without split-K partial sums.  Falls back to n ucfvit_gemm calls when the set is not groupable. */
+int ucfvit_gemm_grouped(const ucfvit_gemm_desc* descs, int64_t n, void* stream);
+
 /* column sums  out[n] (fp32) (+)= sum_m x[m][n]   — bias gradients of every nn.Linear (autograd of :159,190,123,127) */
 int64_t ucfvit_colsum_workspace(int64_t M, int64_t N); /* bytes of fp32 scratch for the deterministic two-stage sum */
 int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate, void* workspace, int dtype,

@@ -288,3 +288,25 @@ def test_gemm_v2_wgrad_splitk(Mtok, N, K):
     assert torch.equal(dw, dw2), "split-K reduction must be deterministic"
     ops.linear_wgrad(dy.to(DEV), x.to(DEV), out=dw, accumulate=True)
     assert rel_err(dw, 2 * ref) < 1e-4
+
+
+@pytest.mark.parametrize("Mtok,D", [(1000, 256), (3302, 512)])
+def test_wgrad_grouped_one_launch(Mtok, D):
+    """the four weight gradients of a Block as one grouped persistent launch (ucfvit_gemm_grouped), ragged token count"""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(D)
+    shapes = [(3 * D, D), (D, D), (4 * D, D), (D, 4 * D)]       # (N_out, K_in) of qkv, proj, fc1, fc2
+    items, refs = [], []
+    for i, (n, k) in enumerate(shapes):
+        dy = torch.randn(Mtok, n, generator=gen).bfloat16()
+        x = torch.randn(Mtok, k, generator=gen).bfloat16()
+        out = torch.full((n, k), 0.5, dtype=torch.float32, device=DEV) if i == 1 else None     # one problem accumulates
+        items.append((dy.to(DEV), x.to(DEV), out, i == 1))
+        refs.append(dy.double().T @ x.double() + (0.5 if i == 1 else 0.0))
+    outs = ops.wgrad_grouped(items)
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < 1e-4
+    outs2 = ops.wgrad_grouped([(a, b, None, False) for a, b, _, _ in items])
+    outs3 = ops.wgrad_grouped([(a, b, None, False) for a, b, _, _ in items])
+    for a, b in zip(outs2, outs3):
+        assert torch.equal(a, b)

@@ -30,7 +30,39 @@ def _ret_grad(g, like):
 
 
 # ---------------------------------------------------------------------------------------------- param-grad helpers
-def _wgrad(weight, dy2, x2):
+class WgradQueue:
+    """Weight gradients of one Block are off the critical path of backward: they are collected and issued as ONE grouped
+    launch (ucfvit_gemm_grouped) when the Block's backward ends, filling the CUs without split-K partial sums."""
+
+    def __init__(self):
+        self.items, self.rets = [], []
+
+    def add(self, weight, dy2, x2):
+        out, acc = grad_target(weight)
+        o2 = out.view(out.shape[0], -1) if out is not None else None
+        if o2 is None:
+            o2 = torch.empty((dy2.shape[1], x2.shape[1]), dtype=torch.float32, device=dy2.device)
+            ret = o2.view(weight.shape)
+        else:
+            ret = None if acc else out
+        self.items.append((dy2, x2, o2, acc))
+        return ret
+
+    def flush(self):
+        if self.items:
+            ops.wgrad_grouped(self.items)
+            self.items = []
+
+
+# Measured (round 1): the grouped 256x256 ping-pong launch runs the KS x KS weight-gradient problem at ~0.45 PFLOP/s because both
+# operands need hardware-transposed LDS reads (2x the DS instructions + per-fragment address arithmetic), slower than the
+# 128x128 split-K kernel (0.45-0.8 PFLOP/s); so grouping is opt-in until that read path is cheaper.
+_GROUP_WGRAD = __import__("os").environ.get("UCFVIT_WGRAD_GROUPED", "0") == "1"
+
+
+def _wgrad(weight, dy2, x2, queue=None):
+    if _GROUP_WGRAD and queue is not None and dy2.dtype == torch.bfloat16:
+        return queue.add(weight, dy2, x2)
     out, acc = grad_target(weight)
     o2 = out.view(out.shape[0], -1) if out is not None else None
     r = ops.linear_wgrad(dy2, x2, out=o2, accumulate=acc)
@@ -109,15 +141,15 @@ def _attn_fwd(x2, B, N, H, wqkv, bqkv, wproj, bproj, residual, tp=None):
     return y, (qkv, o, lse)
 
 
-def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs, tp=None):
+def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs, tp=None, wq=None):
     qkv, o, lse = saved
     dh = wproj.shape[0] // H
     H = H // tp.size if tp else H
-    g_projw = _wgrad(p_projw, dy2, o) if needs[2] else None
+    g_projw = _wgrad(p_projw, dy2, o, wq) if needs[2] else None
     g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
     do = _dgrad(dy2, p_projw, wproj)
     dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
-    g_qkvw = _wgrad(p_qkvw, dqkv, x2) if needs[0] else None
+    g_qkvw = _wgrad(p_qkvw, dqkv, x2, wq) if needs[0] else None
     g_qkvb = _bgrad(p_qkvb, dqkv) if (p_qkvb is not None and needs[1]) else None
     dx = _dgrad(dqkv, p_qkvw, wqkv)
     if tp:
@@ -136,12 +168,12 @@ def _mlp_fwd(x2, w1, b1, w2, b2, residual, tp=None):
     return y, (h, a)
 
 
-def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None):
+def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=None):
     h, a = saved
-    g_w2 = _wgrad(p_w2, dy2, a) if needs[2] else None
+    g_w2 = _wgrad(p_w2, dy2, a, wq) if needs[2] else None
     g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
     dh = _dgrad(dy2, p_w2, w2, aux=h)                                  # dgrad fused with gelu'(h)
-    g_w1 = _wgrad(p_w1, dh, x2) if needs[0] else None
+    g_w1 = _wgrad(p_w1, dh, x2, wq) if needs[0] else None
     g_b1 = _bgrad(p_b1, dh) if (p_b1 is not None and needs[1]) else None
     dx = _dgrad(dh, p_w1, w1)
     if tp:
@@ -270,10 +302,12 @@ class BlockFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         c = lambda p: compute_param(p, cdtype)
         dy2 = _as(dy, cdtype).reshape(x2.shape)
-        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp)
+        wq = WgradQueue()
+        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq)
         dx1, g_n2w, g_n2b = _ln_bwd(dln2, x1, c(n2w), mean2, rstd2, n2w, n2b, dres=dy2)        # + residual branch
-        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7], tp)
+        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7], tp, wq)
         dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1)
+        wq.flush()                                                                              # the Block's 4 weight gradients, one launch
         return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None)
 
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ucfvit_last_error": (c_char_p, []),
     "ucfvit_gemm_workspace": (c_int64, [POINTER(GemmDesc)]),
     "ucfvit_gemm": (c_int, [POINTER(GemmDesc), _P]),
+    "ucfvit_gemm_grouped": (c_int, [POINTER(GemmDesc), _I64, _P]),
     "ucfvit_colsum_workspace": (c_int64, [_I64, _I64]),
     "ucfvit_colsum": (c_int, [_P, _P, _I64, _I64, _I64, _I, _P, _I, _P]),
     "ucfvit_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P]),

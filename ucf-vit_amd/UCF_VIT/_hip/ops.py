@@ -81,6 +81,32 @@ def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None,
     return out
 
 
+def wgrad_grouped(items):
+    """items: list of (dy2 [M,N], x2 [M,K], out fp32 [N,K] or None, accumulate) -> list of dW tensors; ONE launch when groupable"""
+    L = _l.load()
+    n = len(items)
+    outs = []
+    arr = (_l.GemmDesc * n)()
+    for i, (dy2, x2, out, acc) in enumerate(items):
+        _chk(dy2, "wgrad.dy"), _chk(x2, "wgrad.x")
+        Mtok, N = dy2.shape
+        K = x2.shape[1]
+        if out is None:
+            out = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+        outs.append(out)
+        d = arr[i]
+        d.A, d.B, d.C = dy2.data_ptr(), x2.data_ptr(), out.data_ptr()
+        d.bias = d.residual = d.aux_in = d.aux_out = None
+        d.M, d.N, d.K = N, K, Mtok
+        d.lda, d.ldb, d.ldc, d.ldr, d.ldaux = dy2.stride(0), x2.stride(0), out.stride(0), 0, 0
+        d.a_layout, d.b_layout = LAYOUT_KS, LAYOUT_KS
+        d.dtype, d.out_dtype = dt(dy2), F32
+        d.act, d.accumulate, d.alpha = ACT_NONE, 1 if acc else 0, 1.0
+        d.workspace, d.workspace_bytes = None, 0
+    _l.check(L.ucfvit_gemm_grouped(arr, n, _stream()), "ucfvit_gemm_grouped")
+    return outs
+
+
 def linear_fwd(x2, w, b=None, act=ACT_NONE, residual=None, aux_out=None, out=None):
     """y[M,N] = act(x2[M,K]·w[N,K]ᵀ + b) + residual   (nn.Linear forward, building_blocks.py:123,127,159,190)"""
     M, K = x2.shape

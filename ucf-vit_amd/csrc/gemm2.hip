@@ -392,14 +392,26 @@ template <int LAYOUT> __device__ __forceinline__ int64_t k_byte_off(int k0, int6
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
 
+// up to 4 GEMMs of one launch (same K, layouts and output type): the weight gradients of a transformer block
+struct Problem3 {
+    const void* A;
+    const void* B;
+    void* C;
+    int64_t lda, ldb, ldc;
+    int M, N, tiles_m, tiles_n, tile_start, accumulate;
+};
+struct Groups3 {
+    Problem3 p[4];
+    int n, total_tiles;
+};
+
 template <int LA, int LB, typename OutT>
-__global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C, int M, int N,
-                                                     int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m, int tiles_n, int k_per_split) {
+__global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, int k_per_split) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int nwg = tiles_m * tiles_n;
+    const int nwg = gt.total_tiles;
     const int G = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -411,21 +423,35 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
     const int k_end = min(K, k_begin + k_per_split);
     const int nk = (k_end - k_begin + BK2 - 1) / BK2;
     const int klast = k_end - k_begin - (nk - 1) * BK2;      // valid contraction extent of the last K-tile (1..64)
-    float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
-
     constexpr int PADW = TN + 4, LPR = TN / 8, RPI = 64 / LPR;
     const int prow = lane / LPR, pcol = (lane % LPR) * 8;
 
     int it = 0;
     int m0, n0;
+    // current problem of this workgroup (grouped launches carry up to 4 GEMMs that share K and the layouts)
+    const char *Ab, *Bb;
+    OutT* C;
+    int M, N, accum;
+    int64_t lda, ldb, ldc;
+#define PP_SELECT(t_, Ab_, Bb_, C_, M_, N_, lda_, ldb_, ldc_, acc_, m0_, n0_)                 \
+    do {                                                                                       \
+        int gi = 0;                                                                            \
+        _Pragma("unroll") for (int q = 1; q < 4; ++q) if (q < gt.n && (t_) >= gt.p[q].tile_start) gi = q; \
+        const Problem3& P = gt.p[gi];                                                          \
+        Ab_ = reinterpret_cast<const char*>(P.A);                                              \
+        Bb_ = reinterpret_cast<const char*>(P.B);                                              \
+        C_ = reinterpret_cast<OutT*>(P.C);                                                     \
+        M_ = P.M; N_ = P.N; lda_ = P.lda; ldb_ = P.ldb; ldc_ = P.ldc; acc_ = P.accumulate;     \
+        tile_origin((t_) - P.tile_start, P.tiles_m, P.tiles_n, BM, BN, m0_, n0_);              \
+    } while (0)
     {
         const int first = min(G, nwg);
         if ((int)blockIdx.x >= first) return;
-        tile_origin(xcd_remap(blockIdx.x, first), tiles_m, tiles_n, BM, BN, m0, n0);
+        const int t0 = xcd_remap(blockIdx.x, first);
+        PP_SELECT(t0, Ab, Bb, C, M, N, lda, ldb, ldc, accum, m0, n0);
     }
+    float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
     // prologue: both groups issue their halves of the first K-tile, wait, barrier
-    const char* Ab = reinterpret_cast<const char*>(A);
-    const char* Bb = reinterpret_cast<const char*>(B);
     unsigned offA[4], offB[4];
     half_offsets<LA, BM>(offA, lda, m0, M, grp, w4, lane);
     half_offsets<LB, BN>(offB, ldb, n0, N, grp, w4, lane);
@@ -446,7 +472,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
         const int next_base = (round + 1) * G;
         const int next_cnt = min(G, nwg - next_base);
         const bool has_next = (int)blockIdx.x < next_cnt;
-        if (has_next) tile_origin(next_base + xcd_remap(blockIdx.x, next_cnt), tiles_m, tiles_n, BM, BN, nm0, nn0);
+        const char *nAb = Ab, *nBb = Bb;
+        OutT* nC = C;
+        int nM = M, nN = N, naccum = accum;
+        int64_t nlda = lda, nldb = ldb, nldc = ldc;
+        if (has_next) {
+            const int tn_ = next_base + xcd_remap(blockIdx.x, next_cnt);
+            PP_SELECT(tn_, nAb, nBb, nC, nM, nN, nlda, nldb, nldc, naccum, nm0, nn0);
+        }
 
         f32x4 acc[FM][FN];
 #pragma unroll
@@ -467,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                         \
     } while (0)
-#define PP_ISSUE_ONE(LAY_, BR_, base_, ld_, off_, r0n_, Rn_, ldsoff_, kt_)                       \
+#define PP_ISSUE_ONE(LAY_, BR_, base_, ld_, off_, nbase_, nld_, r0n_, Rn_, ldsoff_, kt_)         \
     do {                                                                                       \
         char* nb = smem + ((it + 1) & 1) * BUF + (ldsoff_);                                    \
         if ((kt_) + 1 < nk) {                                                                  \
@@ -476,15 +509,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
             else                                                                               \
                 issue_half<BR_>(base_ + k_byte_off<LAY_>(k_begin + ((kt_) + 1) * BK2, ld_), off_, nb, grp, w4); \
         } else if (has_next) {                                                                 \
-            half_offsets<LAY_, BR_>(off_, ld_, r0n_, Rn_, grp, w4, lane);  /* offsets now belong to the next tile */ \
+            half_offsets<LAY_, BR_>(off_, nld_, r0n_, Rn_, grp, w4, lane);  /* offsets now belong to the next tile */ \
             if (nk == 1 && klast < BK2)                                                        \
-                issue_half_tail<LAY_, BR_>(base_ + k_byte_off<LAY_>(k_begin, ld_), off_, nb, grp, w4, lane, klast); \
+                issue_half_tail<LAY_, BR_>(nbase_ + k_byte_off<LAY_>(k_begin, nld_), off_, nb, grp, w4, lane, klast); \
             else                                                                               \
-                issue_half<BR_>(base_ + k_byte_off<LAY_>(k_begin, ld_), off_, nb, grp, w4);    \
+                issue_half<BR_>(nbase_ + k_byte_off<LAY_>(k_begin, nld_), off_, nb, grp, w4);  \
         }                                                                                      \
     } while (0)
-#define PP_ISSUE_B(kt_) PP_ISSUE_ONE(LB, BN, Bb, ldb, offB, nn0, N, A_BYTES, kt_)
-#define PP_ISSUE_A(kt_) PP_ISSUE_ONE(LA, BM, Ab, lda, offA, nm0, M, 0, kt_)
+#define PP_ISSUE_B(kt_) PP_ISSUE_ONE(LB, BN, Bb, ldb, offB, nBb, nldb, nn0, nN, A_BYTES, kt_)
+#define PP_ISSUE_A(kt_) PP_ISSUE_ONE(LA, BM, Ab, lda, offA, nAb, nlda, nm0, nM, 0, kt_)
 
         // One program for both groups; G1 runs it one barrier interval behind G0 (extra barrier before / after the loop).
         if (grp == 1) PP_BARRIER();
@@ -508,6 +541,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
         if (grp == 0) PP_BARRIER();
 #undef PP_READ
 #undef PP_COMPUTE
+#undef PP_SELECT
 #undef PP_ISSUE_ONE
 #undef PP_ISSUE_A
 #undef PP_ISSUE_B
@@ -575,9 +609,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
                 }
-                OutT* cp = C + (int64_t)m * ep.ldc + n;
+                OutT* cp = C + (int64_t)m * ldc + n;
                 if constexpr (sizeof(OutT) == 2) {
-                    if (ep.accumulate) {
+                    if (accum) {
                         const Vec16<bf16> old = *reinterpret_cast<const Vec16<bf16>*>(cp);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += old.get(r);
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
                         o0[r] = v[r];
                         o1[r] = v[4 + r];
                     }
-                    if (ep.accumulate) {
+                    if (accum) {
                         o0 += *reinterpret_cast<const f32x4*>(cp);
                         o1 += *reinterpret_cast<const f32x4*>(cp + 4);
                     }
@@ -605,6 +639,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const bf16* __restrict__ A, 
         if (!has_next) break;
         m0 = nm0;
         n0 = nn0;
+        Ab = nAb; Bb = nBb; C = nC; M = nM; N = nN; accum = naccum; lda = nlda; ldb = nldb; ldc = nldc;
         // the next tile's first K-tile was issued during the last K-tile and waited for (vmcnt(0) + barrier) at its end;
         // the epilogue's LDS staging of every wave must be finished before that buffer's partner is refilled:
         __builtin_amdgcn_sched_barrier(0);
@@ -715,8 +750,7 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
 }
 
 template <int LA, int LB, typename OutT>
-int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
-    const int tiles_m = (int)((d->M + 255) / 256), tiles_n = (int)((d->N + 255) / 256);
+int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
     constexpr size_t smem = 2 * (size_t)(256 + 256) * 128;
     auto kern = gemm3_kernel<LA, LB, OutT>;
     static bool done = false;
@@ -728,14 +762,37 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
         }
         done = true;
     }
-    const int ntiles = tiles_m * tiles_n;
-    int cap = 256 / p.splits;
+    int cap = 256 / splits;
     if (cap < 1) cap = 1;
-    const int gx = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL(kern, dim3(gx, p.splits), dim3(512), smem, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C, (int)d->M, (int)d->N,
-                       (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n, p.k_per_split);
+    const int gx = gt.total_tiles < cap ? gt.total_tiles : cap;
+    hipLaunchKernelGGL(kern, dim3(gx, splits), dim3(512), smem, s, gt, K, ep, k_per_split);
     UCF_LAUNCH_CHECK("ucfvit_gemm(v3 ping-pong)");
     return UCFVIT_OK;
+}
+
+inline void fill_problem(Problem3& P, const ucfvit_gemm_desc* d, int tile_start) {
+    P.A = d->A;
+    P.B = d->B;
+    P.C = d->C;
+    P.lda = d->lda;
+    P.ldb = d->ldb;
+    P.ldc = d->ldc;
+    P.M = (int)d->M;
+    P.N = (int)d->N;
+    P.tiles_m = (int)((d->M + 255) / 256);
+    P.tiles_n = (int)((d->N + 255) / 256);
+    P.tile_start = tile_start;
+    P.accumulate = d->accumulate;
+}
+
+template <int LA, int LB, typename OutT>
+int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
+    Groups3 gt;
+    memset(&gt, 0, sizeof(gt));
+    fill_problem(gt.p[0], d, 0);
+    gt.n = 1;
+    gt.total_tiles = gt.p[0].tiles_m * gt.p[0].tiles_n;
+    return launch3g<LA, LB, OutT>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
 }
 
 static bool pp_enabled() {
@@ -824,4 +881,56 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     else
         return 0;
     return rc == UCFVIT_OK ? 1 : rc;
+}
+
+
+// Grouped launch: n <= 4 epilogue-free GEMMs with identical K, layouts and dtypes (the four weight gradients of a Block) run
+// as ONE persistent ping-pong launch over the union of their 256x256 tiles — no split-K, no partial-sum slabs.
+extern "C" int ucfvit_gemm_grouped(const ucfvit_gemm_desc* descs, int64_t n, void* stream) {
+    UCF_CHECK_ARG(descs && n >= 1 && n <= 4, "ucfvit_gemm_grouped: need 1..4 descriptors");
+    const ucfvit_gemm_desc& d0 = descs[0];
+    bool fast = d0.dtype == UCFVIT_BF16 && pp_enabled() && d0.K >= 128;
+    for (int64_t i = 0; i < n && fast; ++i) {
+        const ucfvit_gemm_desc& d = descs[i];
+        const int64_t a_contig = (d.a_layout == UCFVIT_LAYOUT_KC) ? d.K : d.M;
+        const int64_t b_contig = (d.b_layout == UCFVIT_LAYOUT_KC) ? d.K : d.N;
+        const int64_t a_bytes = ((d.a_layout == UCFVIT_LAYOUT_KC ? d.M : d.K) * d.lda) * 2;
+        const int64_t b_bytes = ((d.b_layout == UCFVIT_LAYOUT_KC ? d.N : d.K) * d.ldb) * 2;
+        fast = d.K == d0.K && d.dtype == d0.dtype && d.out_dtype == d0.out_dtype && d.a_layout == d0.a_layout && d.b_layout == d0.b_layout &&
+               !d.bias && !d.residual && !d.aux_in && !d.aux_out && d.act == UCFVIT_ACT_NONE && d.alpha == 1.0f && d.A && d.B && d.C &&
+               d.M >= 128 && d.N >= 128 && ucf_is_aligned16(d.A) && ucf_is_aligned16(d.B) && ucf_is_aligned16(d.C) && d.lda % 8 == 0 &&
+               d.ldb % 8 == 0 && d.ldc % 8 == 0 && a_contig % 8 == 0 && b_contig % 8 == 0 && d.N % 8 == 0 && a_bytes < (1ll << 32) &&
+               b_bytes < (1ll << 32) &&
+               !((d.a_layout == UCFVIT_LAYOUT_KC || d.b_layout == UCFVIT_LAYOUT_KC) && d.K % 8 != 0);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (!fast) {   // not groupable: run them one by one through the ordinary dispatcher
+        for (int64_t i = 0; i < n; ++i) {
+            const int rc = ucfvit_gemm(&descs[i], stream);
+            if (rc) return rc;
+        }
+        return UCFVIT_OK;
+    }
+    Groups3 gt;
+    memset(&gt, 0, sizeof(gt));
+    int tiles = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        fill_problem(gt.p[i], &descs[i], tiles);
+        tiles += gt.p[i].tiles_m * gt.p[i].tiles_n;
+    }
+    gt.n = (int)n;
+    gt.total_tiles = tiles;
+    Epi2 ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.alpha = 1.0f;
+    const int K = (int)d0.K;
+    const int kps = ((K + BK2 - 1) / BK2) * BK2;
+    const int la = d0.a_layout, lb = d0.b_layout;
+#define G3(LA_, LB_)                                                                                            \
+    (d0.out_dtype == UCFVIT_F32 ? launch3g<LA_, LB_, float>(gt, K, ep, 1, kps, s) : launch3g<LA_, LB_, bf16>(gt, K, ep, 1, kps, s))
+    if (la == 0 && lb == 0) return G3(0, 0);
+    if (la == 0 && lb == 1) return G3(0, 1);
+    if (la == 1 && lb == 1) return G3(1, 1);
+    return G3(1, 0);
+#undef G3
 }
