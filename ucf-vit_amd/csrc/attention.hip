@@ -11,7 +11,24 @@
 // LDS tiles through ds_read_b64_tr_b16 (hardware transpose).  The backward pass uses the same trick with the key on
 // the lane for dK/dV and the query on the lane for dQ, recomputing P from the saved log-sum-exp; no atomics, so
 // gradients are bitwise reproducible.
+#include <stdlib.h>
+
 #include "common.h"
+
+// attention_short.hip: whole-sequence-in-LDS kernels for N <= 256 (return 1 = handled, 0 = not applicable, <0 = error)
+int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
+                               hipStream_t s);
+int ucfvit_attention_short_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
+                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s);
+
+static bool short_enabled() {
+    static int flag = -1;
+    if (flag < 0) {
+        const char* e = getenv("UCFVIT_ATTN_STREAM");
+        flag = (e && e[0] == '1') ? 0 : 1;
+    }
+    return flag == 1;
+}
 
 namespace {
 
@@ -206,13 +223,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
                 mx = fmaxf(mx, t);
             }
         const float m_new = fmaxf(m, group_max(mx));  // finite: every tile holds at least one valid key
-        const float alpha = exp2f(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
                 s[kb][r] = p;
                 psum += p;
             }
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * KT + kb * 16 + 4 * g + r;
-                const float p = key < N ? exp2f(s[r] * scale_log2e - my_lse) : 0.f;
+                const float p = key < N ? __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -my_lse)) : 0.f;
                 ds[kb][r] = p * (dp[r] - my_delta);
             }
         }
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[r] * scale_log2e - l4[r]);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -l4[r]));
                 pm[qb][r] = p;
                 ds[qb][r] = p * (dp[r] - d4[r]);
             }
@@ -487,6 +504,14 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
     hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, B,
                        (int)N, (int)H);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");
+    // measured (ViT-L, N=197, B=166): the resident backward kernels (541 us) are slower than the streaming pair (430 us), the
+    // resident forward (106 us) is faster than the streaming one (115 us): backward stays streaming unless asked otherwise
+    static const bool short_bwd = [] { const char* e = getenv("UCFVIT_ATTN_SHORT_BWD"); return e && e[0] == '1'; }();
+    if (short_enabled() && short_bwd) {
+        const int rc = ucfvit_attention_short_bwd(qkv, dout, lse, delta, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
+        if (rc == 1) return UCFVIT_OK;
+        if (rc < 0) return rc;
+    }
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)H, (unsigned)B);
     const float sl2 = scale * 1.44269504088896340736f;
     constexpr size_t smem_dq = 2 * AT<T, DH>::TILE_BYTES;
@@ -531,6 +556,11 @@ extern "C" int ucfvit_attention_fwd(const void* qkv, void* out, float* lse, int6
     int rc = check_attn_args("ucfvit_attention_fwd", B, N, H, dh, dtype);
     if (rc) return rc;
     UCF_CHECK_ARG(ucf_is_aligned16(qkv) && ucf_is_aligned16(out), "ucfvit_attention_fwd: pointers must be 16-byte aligned");
+    if (short_enabled()) {
+        rc = ucfvit_attention_short_fwd(qkv, out, lse, B, N, H, dh, scale, dtype, (hipStream_t)stream);
+        if (rc == 1) return UCFVIT_OK;
+        if (rc < 0) return rc;
+    }
     ATTN_DISPATCH(attn_fwd_launch, qkv, out, lse, B, N, H, scale, (hipStream_t)stream);
 }
 

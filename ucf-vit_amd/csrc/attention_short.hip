@@ -1,0 +1,444 @@
+// Short-sequence fused attention for gfx950 (N <= 256 tokens: ViT 224^2/16 has N = 197, MAE encoder 49, MAE decoder 196).
+//
+// One workgroup per (batch, head): the whole K and V (forward, dQ) or Q and dO (dK/dV) of that head live in LDS for the
+// lifetime of the workgroup — they are read from HBM/L2 once instead of once per 64-query tile — and the softmax is single
+// pass (all scores of a query row are in registers at once: no running max, no rescaling of the output accumulator).
+// Work is cut in 16-row MFMA blocks, so N = 197 costs 13 x 13 blocks (208^2) instead of the 4 x 4 tiles of 64 (256^2) of the
+// streaming kernel.  Same "softmax index on the lane" layout as attention.hip: Sᵀ[key][q] = K·Qᵀ, accumulators feed the
+// next MFMA as operands, Vᵀ / Kᵀ / Qᵀ / dOᵀ come out of the row-major LDS images through ds_read_b64_tr_b16.
+// NB = number of 16-row blocks (compile time); rows >= N are zero-filled and masked.
+#include "common.h"
+
+namespace {
+
+constexpr int AS_THREADS = 256;
+
+template <typename T> struct MmaS;
+template <> struct MmaS<bf16> {
+    typedef bf16x8 frag_t;
+    static __device__ __forceinline__ void mma(f32x4& acc, const frag_t& a, const frag_t& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+};
+template <> struct MmaS<float> {
+    typedef f32x4 frag_t;
+    static __device__ __forceinline__ void mma(f32x4& acc, const frag_t& a, const frag_t& b) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int DH, int NB> struct AS {
+    static constexpr int EPV = 16 / sizeof(T);
+    static constexpr int RB = DH * sizeof(T);       // image row bytes
+    static constexpr int SPR = RB / 16;             // 16-B slots per row
+    static constexpr int NCH = DH / (4 * EPV);      // head-dim chunks (contraction over d)
+    static constexpr int NDB = DH / 16;             // 16-wide head-dim blocks (outputs)
+    static constexpr int BPC = (4 * EPV) / 16;      // 16-row blocks per row chunk (bf16: 2, fp32: 1)
+    static constexpr int NRC = (NB + BPC - 1) / BPC;  // row chunks (contraction over keys / queries)
+    static constexpr int ROWS = NRC * BPC * 16;     // rows held in an LDS image (padded to whole chunks)
+    static constexpr int IMG = ROWS * RB;
+    typedef typename MmaS<T>::frag_t frag_t;
+};
+
+template <int SPR> __device__ __forceinline__ int swz_s(int row) {
+    if (SPR == 4) return (0x1230 >> (((row >> 2) & 3) * 4)) & 3;
+    if (SPR == 8) return row & 7;
+    return row & 15;
+}
+template <typename T, int DH> __device__ __forceinline__ int img_off(int row, int slot) {
+    constexpr int RB = DH * sizeof(T), SPR = RB / 16;
+    return row * RB + ((slot ^ swz_s<SPR>(row)) << 4);
+}
+
+// global rows [0, R) of a [.., row_stride] matrix -> LDS image of ROWS rows (rows >= R zero)
+template <typename T, int DH, int ROWS>
+__device__ __forceinline__ void load_image(char* lds, const T* __restrict__ base, int64_t row_stride, int R, int tid) {
+    constexpr int EPV = 16 / sizeof(T), SPR = DH * sizeof(T) / 16;
+    constexpr int NIT = (ROWS * SPR + AS_THREADS - 1) / AS_THREADS;
+    u32x4 v[NIT];
+    // all loads in flight first (one HBM/L2 round trip for the whole image), then the LDS stores
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int p = tid + i * AS_THREADS;
+        const int row = p / SPR, slot = p % SPR;
+        v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (p < ROWS * SPR && row < R) v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + slot * EPV);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int p = tid + i * AS_THREADS;
+        if (p < ROWS * SPR) *reinterpret_cast<u32x4*>(lds + img_off<T, DH>(p / SPR, p % SPR)) = v[i];
+    }
+}
+
+template <typename T, int DH>
+__device__ __forceinline__ typename MmaS<T>::frag_t s_frag_row(const char* lds, int rb, int c, int lane) {
+    const int row = rb * 16 + (lane & 15), g = lane >> 4;
+    return *reinterpret_cast<const typename MmaS<T>::frag_t*>(lds + img_off<T, DH>(row, 4 * c + g));
+}
+template <typename T, int DH>
+__device__ __forceinline__ typename MmaS<T>::frag_t s_frag_tr(const char* lds, int rc, int db, int lane) {
+    typedef typename MmaS<T>::frag_t frag_t;
+    const int g = lane >> 4, i = lane & 15;
+    if constexpr (sizeof(T) == 2) {
+        const int q = i >> 2, p = i & 3;
+        const int slot = 2 * db + (p >> 1), sub = (p & 1) * 8;
+        const int r_lo = 32 * rc + 4 * g + q;
+        const char* a_lo = lds + img_off<T, DH>(r_lo, slot) + sub;
+        const char* a_hi = lds + img_off<T, DH>(r_lo + 16, slot) + sub;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a_lo));
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a_hi));
+        short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(frag_t, r);
+    } else {
+        const int slot = 4 * db + (i >> 2), sub = (i & 3) * 4;
+        f32x4 r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r[s] = *reinterpret_cast<const float*>(lds + img_off<T, DH>(16 * rc + 4 * g + s, slot) + sub);
+        return __builtin_bit_cast(frag_t, r);
+    }
+}
+// accumulator blocks -> operand fragment of row chunk rc; blocks >= nb contribute zeros
+template <typename T, int NBLK> __device__ __forceinline__ typename MmaS<T>::frag_t s_frag_acc(const f32x4 (&acc)[NBLK], int rc) {
+    typedef typename MmaS<T>::frag_t frag_t;
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = (bf16)acc[2 * rc][j];
+            r[4 + j] = (2 * rc + 1 < NBLK) ? (bf16)acc[(2 * rc + 1 < NBLK) ? 2 * rc + 1 : 0][j] : (bf16)0.f;
+        }
+        return __builtin_bit_cast(frag_t, r);
+    } else {
+        return __builtin_bit_cast(frag_t, acc[rc]);
+    }
+}
+template <typename T, int DH>
+__device__ __forceinline__ typename MmaS<T>::frag_t s_frag_global(const T* __restrict__ base, int64_t row_stride, int row, int R, int c, int lane) {
+    typedef typename MmaS<T>::frag_t frag_t;
+    const int g = lane >> 4;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < R) v = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + (4 * c + g) * (16 / (int)sizeof(T)));
+    return __builtin_bit_cast(frag_t, v);
+}
+__device__ __forceinline__ float gmax(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float gsum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// =====================================================================================================================
+// forward: wave handles 16-query blocks qb = wave, wave+4, ...
+// =====================================================================================================================
+template <typename T, int DH, int NB, bool EXACT>
+__global__ __launch_bounds__(AS_THREADS) void attn_s_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse, int N,
+                                                                 int H, float scale_log2e) {
+    typedef AS<T, DH, NB> A;
+    typedef typename A::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;
+    char* ldsV = smem + A::IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x % H;
+    const int64_t b = blockIdx.x / H;
+    const int D = H * DH;
+    const int64_t rs = 3 * (int64_t)D;
+    const T* qbase = qkv + b * N * rs + h * DH;
+    load_image<T, DH, A::ROWS>(ldsK, qbase + D, rs, N, tid);
+    load_image<T, DH, A::ROWS>(ldsV, qbase + 2 * D, rs, N, tid);
+    __syncthreads();
+    const int nqb = (N + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int q = qb * 16 + li;
+        frag_t qf[A::NCH];
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
+        f32x4 s[NB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < A::NCH; ++c) MmaS<T>::mma(s[kb], s_frag_row<T, DH>(ldsK, kb, c, lane), qf[c]);
+            if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) {   // only the ragged / padding key blocks pay for masking
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kb][r] = (kb * 16 + 4 * g + r < N) ? s[kb][r] : -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][r]);
+        }
+        // softmax in the log2 domain with the scale folded into one fma per score: p = 2^(s*c - max*c)   (c > 0)
+        const float m = gmax(mx) * scale_log2e;
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m));
+                s[kb][r] = p;
+                l += p;
+            }
+        const float lt = gsum(l);
+        f32x4 o[A::NDB];
+#pragma unroll
+        for (int d = 0; d < A::NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rc = 0; rc < A::NRC; ++rc) {
+            const frag_t pf = s_frag_acc<T, NB>(s, rc);
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) MmaS<T>::mma(o[d], s_frag_tr<T, DH>(ldsV, rc, d, lane), pf);
+        }
+        if (q < N) {
+            const float inv = 1.f / lt;
+            T* op = out + (b * N + q) * D + h * DH;
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) {
+                Vec4<T> v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v.set(r, o[d][r] * inv);
+                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            }
+            if (g == 0) lse[(b * H + h) * N + q] = m + log2f(lt);
+        }
+    }
+}
+
+// =====================================================================================================================
+// backward dQ: K, V resident; wave handles query blocks
+// =====================================================================================================================
+template <typename T, int DH, int NB, bool EXACT>
+__global__ __launch_bounds__(AS_THREADS) void attn_s_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                const float* __restrict__ delta, T* __restrict__ dqkv, int N, int H, float scale,
+                                                                float scale_log2e) {
+    typedef AS<T, DH, NB> A;
+    typedef typename A::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;
+    char* ldsV = smem + A::IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x % H;
+    const int64_t b = blockIdx.x / H;
+    const int D = H * DH;
+    const int64_t rs = 3 * (int64_t)D;
+    const T* qbase = qkv + b * N * rs + h * DH;
+    const T* dobase = dout + b * N * (int64_t)D + h * DH;
+    load_image<T, DH, A::ROWS>(ldsK, qbase + D, rs, N, tid);
+    load_image<T, DH, A::ROWS>(ldsV, qbase + 2 * D, rs, N, tid);
+    __syncthreads();
+    const int nqb = (N + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int q = qb * 16 + li;
+        frag_t qf[A::NCH], dof[A::NCH];
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) {
+            qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
+            dof[c] = s_frag_global<T, DH>(dobase, D, q, N, c, lane);
+        }
+        const float my_lse = q < N ? lse[(b * H + h) * N + q] : 0.f;
+        const float my_delta = q < N ? delta[(b * H + h) * N + q] : 0.f;
+        f32x4 ds[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < A::NCH; ++c) {
+                MmaS<T>::mma(s, s_frag_row<T, DH>(ldsK, kb, c, lane), qf[c]);
+                MmaS<T>::mma(dp, s_frag_row<T, DH>(ldsV, kb, c, lane), dof[c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -my_lse));
+                if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) p = (kb * 16 + 4 * g + r < N) ? p : 0.f;     // ragged key block only
+                ds[kb][r] = p * (dp[r] - my_delta);
+            }
+        }
+        f32x4 dq[A::NDB];
+#pragma unroll
+        for (int d = 0; d < A::NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rc = 0; rc < A::NRC; ++rc) {
+            const frag_t f = s_frag_acc<T, NB>(ds, rc);
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) MmaS<T>::mma(dq[d], s_frag_tr<T, DH>(ldsK, rc, d, lane), f);
+        }
+        if (q < N) {
+            T* op = dqkv + (b * N + q) * rs + h * DH;
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) {
+                Vec4<T> v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v.set(r, dq[d][r] * scale);
+                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
+// backward dK / dV: Q, dO (+ lse, delta) resident; wave handles key blocks
+// =====================================================================================================================
+template <typename T, int DH, int NB>
+__global__ __launch_bounds__(AS_THREADS) void attn_s_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta, T* __restrict__ dqkv, int N, int H, float scale,
+                                                                 float scale_log2e) {
+    typedef AS<T, DH, NB> A;
+    typedef typename A::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsQ = smem;
+    char* ldsDO = smem + A::IMG;
+    float* ldsLse = reinterpret_cast<float*>(smem + 2 * A::IMG);   // [ROWS]
+    float* ldsDelta = ldsLse + A::ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.x % H;
+    const int64_t b = blockIdx.x / H;
+    const int D = H * DH;
+    const int64_t rs = 3 * (int64_t)D;
+    const T* qbase = qkv + b * N * rs + h * DH;
+    const T* dobase = dout + b * N * (int64_t)D + h * DH;
+    load_image<T, DH, A::ROWS>(ldsQ, qbase, rs, N, tid);
+    load_image<T, DH, A::ROWS>(ldsDO, dobase, D, N, tid);
+    for (int i = tid; i < A::ROWS; i += AS_THREADS) {
+        ldsLse[i] = i < N ? lse[(b * H + h) * N + i] : INFINITY;    // +inf -> P = 0 for padding queries
+        ldsDelta[i] = i < N ? delta[(b * H + h) * N + i] : 0.f;
+    }
+    __syncthreads();
+    const int nkb = (N + 15) / 16;
+    for (int kb = wave; kb < nkb; kb += 4) {
+        const int key = kb * 16 + li;
+        frag_t kf[A::NCH], vf[A::NCH];
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) {
+            kf[c] = s_frag_global<T, DH>(qbase + D, rs, key, N, c, lane);
+            vf[c] = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, c, lane);
+        }
+        f32x4 pm[NB], ds[NB];
+#pragma unroll
+        for (int qb = 0; qb < NB; ++qb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < A::NCH; ++c) {
+                MmaS<T>::mma(s, s_frag_row<T, DH>(ldsQ, qb, c, lane), kf[c]);
+                MmaS<T>::mma(dp, s_frag_row<T, DH>(ldsDO, qb, c, lane), vf[c]);
+            }
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsLse + qb * 16 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -l4[r]));
+                pm[qb][r] = p;
+                ds[qb][r] = p * (dp[r] - d4[r]);
+            }
+        }
+        f32x4 dk[A::NDB], dv[A::NDB];
+#pragma unroll
+        for (int d = 0; d < A::NDB; ++d) {
+            dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int rc = 0; rc < A::NRC; ++rc) {
+            const frag_t fp = s_frag_acc<T, NB>(pm, rc);
+            const frag_t fs = s_frag_acc<T, NB>(ds, rc);
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) {
+                MmaS<T>::mma(dv[d], s_frag_tr<T, DH>(ldsDO, rc, d, lane), fp);
+                MmaS<T>::mma(dk[d], s_frag_tr<T, DH>(ldsQ, rc, d, lane), fs);
+            }
+        }
+        if (key < N) {
+            T* kp = dqkv + (b * N + key) * rs + D + h * DH;
+            T* vp = kp + D;
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) {
+                Vec4<T> a, c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a.set(r, dk[d][r] * scale);
+                    c.set(r, dv[d][r]);
+                }
+                *reinterpret_cast<Vec4<T>*>(kp + d * 16 + 4 * g) = a;
+                *reinterpret_cast<Vec4<T>*>(vp + d * 16 + 4 * g) = c;
+            }
+        }
+    }
+}
+
+template <typename K> int big_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return UCFVIT_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        ucfvit_set_error("attention(short): cannot raise dynamic LDS to %zu bytes: %s", bytes, hipGetErrorString(e));
+        return UCFVIT_ERR_HIP;
+    }
+    return UCFVIT_OK;
+}
+
+template <typename T, int DH, int NB>
+int launch_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+    constexpr size_t smem = 2 * AS<T, DH, NB>::IMG;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const dim3 grid((unsigned)(B * H)), block(AS_THREADS);
+    if ((N + 15) / 16 == NB) {
+        if (int rc = big_lds(attn_s_fwd_kernel<T, DH, NB, true>, smem)) return rc;
+        hipLaunchKernelGGL((attn_s_fwd_kernel<T, DH, NB, true>), grid, block, smem, s, (const T*)qkv, (T*)out, lse, (int)N, (int)H, sl2);
+    } else {
+        if (int rc = big_lds(attn_s_fwd_kernel<T, DH, NB, false>, smem)) return rc;
+        hipLaunchKernelGGL((attn_s_fwd_kernel<T, DH, NB, false>), grid, block, smem, s, (const T*)qkv, (T*)out, lse, (int)N, (int)H, sl2);
+    }
+    UCF_LAUNCH_CHECK("ucfvit_attention_fwd(short)");
+    return UCFVIT_OK;
+}
+template <typename T, int DH, int NB>
+int launch_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N, int64_t H, float scale,
+               hipStream_t s) {
+    constexpr size_t smem_dq = 2 * AS<T, DH, NB>::IMG;
+    constexpr size_t smem_dkv = smem_dq + 2 * AS<T, DH, NB>::ROWS * sizeof(float);
+    if (int rc = big_lds(attn_s_dkv_kernel<T, DH, NB>, smem_dkv)) return rc;
+    const float sl2 = scale * 1.44269504088896340736f;
+    if ((N + 15) / 16 == NB) {
+        if (int rc = big_lds(attn_s_dq_kernel<T, DH, NB, true>, smem_dq)) return rc;
+        hipLaunchKernelGGL((attn_s_dq_kernel<T, DH, NB, true>), dim3((unsigned)(B * H)), dim3(AS_THREADS), smem_dq, s, (const T*)qkv, (const T*)dout, lse,
+                           delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
+    } else {
+        if (int rc = big_lds(attn_s_dq_kernel<T, DH, NB, false>, smem_dq)) return rc;
+        hipLaunchKernelGGL((attn_s_dq_kernel<T, DH, NB, false>), dim3((unsigned)(B * H)), dim3(AS_THREADS), smem_dq, s, (const T*)qkv, (const T*)dout, lse,
+                           delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
+    }
+    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(short dq)");
+    hipLaunchKernelGGL((attn_s_dkv_kernel<T, DH, NB>), dim3((unsigned)(B * H)), dim3(AS_THREADS), smem_dkv, s, (const T*)qkv, (const T*)dout, lse,
+                       delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
+    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(short dkv)");
+    return UCFVIT_OK;
+}
+
+}  // namespace
+
+// returns 1 when handled, 0 when the shape is outside the short-sequence kernels (caller streams), <0 on error
+#define AS_PICK(FN, T, DH, ...)                          \
+    do {                                                 \
+        if (nb <= 4) return FN<T, DH, 4>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;   \
+        if (nb <= 8) return FN<T, DH, 8>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;   \
+        if (nb <= 13) return FN<T, DH, 13>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP; \
+        return FN<T, DH, 16>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;               \
+    } while (0)
+
+int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
+                               hipStream_t s) {
+    // bf16 only: the fp32 instantiations exceed the register file (the exact-fp32 parity mode keeps the streaming kernels)
+    if (dtype != UCFVIT_BF16 || N > 256 || (dh != 32 && dh != 64) || B * H >= (1ll << 31)) return 0;
+    const int nb = (int)((N + 15) / 16);
+    if (dh == 64) AS_PICK(launch_fwd, bf16, 64, qkv, out, lse, B, N, H, scale, s);
+    AS_PICK(launch_fwd, bf16, 32, qkv, out, lse, B, N, H, scale, s);
+}
+
+int ucfvit_attention_short_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
+                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s) {
+    if (dtype != UCFVIT_BF16 || N > 256 || (dh != 32 && dh != 64) || B * H >= (1ll << 31)) return 0;
+    const int nb = (int)((N + 15) / 16);
+    if (dh == 64) AS_PICK(launch_bwd, bf16, 64, qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+    AS_PICK(launch_bwd, bf16, 32, qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+}
