@@ -68,3 +68,67 @@ def test_reducer_two_ranks_gloo(bucket_mb, min_buckets):
     for rank, ok, keys_ok, nb in res:
         assert ok, f"rank {rank}: gradients differ from the mean of per-rank gradients"
         assert keys_ok and nb >= min_buckets
+
+
+def _hip_dp_worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from UCF_VIT.simple.arch import VIT
+        from UCF_VIT.utils.metrics import cross_entropy_loss
+        from UCF_VIT.utils.misc import configure_optimizer
+        from UCF_VIT._hip.ddp import HipDataParallel
+        from oracle import ucf_vit_ref as R
+        from det_weights import det_state_dict, det_tensor
+        kw = dict(img_size=[32, 32], patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=2, num_heads=2)
+        ref = R.VIT(**kw)
+        ref.load_state_dict(det_state_dict(ref, 100))
+        m = VIT(**kw)
+        m.load_state_dict(det_state_dict(m, 100 + rank))        # different per rank: the wrap broadcasts rank 0's weights
+        m = m.to("cuda:0")
+        ddp = HipDataParallel(m, bucket_mb=0.05)
+        opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 0.0)
+        xs = [det_tensor((2, 3, 32, 32), 10 + r) for r in range(world)]
+        ys = [torch.tensor([r % 5, (2 * r + 1) % 5]) for r in range(world)]
+        exp = None
+        for r in range(world):
+            ref.zero_grad()
+            torch.nn.CrossEntropyLoss()(ref(xs[r]), ys[r]).backward()
+            g = [p.grad.clone() for p in ref.parameters()]
+            exp = g if exp is None else [a + b for a, b in zip(exp, g)]
+        out = ddp(xs[rank].to("cuda:0"), None, None)
+        cross_entropy_loss(out, ys[rank].to("cuda:0")).backward()
+        torch.cuda.synchronize()
+        from conftest import rel_err
+        bad = [k for (k, p), e in zip(m.named_parameters(), exp) if rel_err(p.grad, e / world) > 1e-3]
+        opt.step()
+        opt.zero_grad()
+        # after an identical update every rank must hold identical weights
+        w = m._ucf_store.flat_p.detach().cpu()
+        w0 = w.clone()
+        dist.broadcast(w0, 0)
+        q.put((rank, bad, bool(torch.equal(w, w0)), "_flat" in opt.state))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_data_parallel_two_ranks_share_one_gpu():
+    """the HIP model + flat-buffer reducer + fused AdamW with world_size 2 (both ranks on the one GPU, gloo transport):
+    gradients = mean over ranks, weights stay identical after the step"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_dp_worker, args=(r, 2, 29571, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, same, flat in res:
+        assert not bad, f"rank {rank}: gradient mismatch in {bad}"
+        assert same and flat

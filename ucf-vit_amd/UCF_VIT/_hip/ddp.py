@@ -108,8 +108,15 @@ class HipDataParallel(nn.Module):
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         view = self.flat_g[lo:hi]
-        if self._hip:
-            w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        if self._hip and dist.get_backend(self.pg) != "gloo":
+            w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)      # RCCL, its own HIP stream
+        elif self._hip:
+            # test transport (several ranks sharing one GPU cannot use RCCL): host-staged, synchronous
+            h = view.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            view.copy_(h.div_(self.world))
+            self._pending[b] = -(1 << 30)
+            return
         else:
             view.div_(self.world)
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

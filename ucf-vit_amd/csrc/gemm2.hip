@@ -700,7 +700,13 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
     } else {
         p->big = 0;
         if (plain_epi && t128 < 384) {
-            int s = (int)((512 + t128 - 1) / t128);          // aim at ~512 workgroups (2 per CU)
+            static int target = 0;
+            if (!target) {
+                const char* e = getenv("UCFVIT_GEMM_SPLIT_TARGET");
+                target = e ? atoi(e) : 512;
+                if (target < 1) target = 512;
+            }
+            int s = (int)(target / t128);                    // largest split that still fits ONE round of resident workgroups (2 per CU)
             const int kmax = (int)(ktiles_all / 8);          // at least 8 K-tiles per slice
             if (s > kmax) s = kmax;
             if (s > 16) s = 16;

@@ -173,37 +173,43 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
-// column sums: workgroup = 16 column-lanes (16 B each) x 16 row-groups; grid.y row chunks -> partial[chunk][N]
+// column sums: a wave covers 64 x 16 B = 1 KiB of contiguous columns of one row (full-line coalescing), the 4 waves of a
+// workgroup take rows r, r+1, r+2, r+3 ...; grid.y row chunks -> partial[chunk][N], reduced in a fixed order afterwards
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t M, int N,
                                                      int64_t ldx, int rows_per_chunk) {
     constexpr int EPV = Vec16<T>::N;
-    __shared__ float red[16][16 * 8 + 4];
-    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int col = (blockIdx.x * 16 + cl) * EPV;
+    __shared__ float red[4][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * EPV;
     const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r_end = min(M, r_begin + rows_per_chunk);
     float acc[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
     if (col < N) {
-        for (int64_t r = r_begin + rg; r < r_end; r += 16) {
+        int64_t r = r_begin + wave;
+        for (; r + 12 < r_end; r += 16) {   // 4 independent loads in flight per lane
+            const Vec16<T> v0 = *reinterpret_cast<const Vec16<T>*>(x + r * ldx + col);
+            const Vec16<T> v1 = *reinterpret_cast<const Vec16<T>*>(x + (r + 4) * ldx + col);
+            const Vec16<T> v2 = *reinterpret_cast<const Vec16<T>*>(x + (r + 8) * ldx + col);
+            const Vec16<T> v3 = *reinterpret_cast<const Vec16<T>*>(x + (r + 12) * ldx + col);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) acc[e] += (v0.get(e) + v1.get(e)) + (v2.get(e) + v3.get(e));
+        }
+        for (; r < r_end; r += 4) {
             const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + r * ldx + col);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) acc[e] += v.get(e);
         }
     }
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) red[rg][cl * EPV + e] = acc[e];
+    for (int e = 0; e < EPV; ++e) red[wave][lane * EPV + e] = acc[e];
     __syncthreads();
-    if (rg == 0 && col < N) {
+    if (wave == 0 && col < N) {
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) s += red[k][cl * EPV + e];
-            partial[(int64_t)blockIdx.y * N + col + e] = s;
-        }
+        for (int e = 0; e < EPV; ++e)
+            partial[(int64_t)blockIdx.y * N + col + e] = (red[0][lane * EPV + e] + red[1][lane * EPV + e]) + (red[2][lane * EPV + e] + red[3][lane * EPV + e]);
     }
 }
 
@@ -218,8 +224,8 @@ __global__ void colsum_scalar_kernel(const T* __restrict__ x, float* __restrict_
 }
 
 inline int colsum_chunks(int64_t M) {
-    int64_t c = (M + 255) / 256;
-    if (c > 64) c = 64;
+    int64_t c = (M + 127) / 128;
+    if (c > 256) c = 256;
     if (c < 1) c = 1;
     return (int)c;
 }
@@ -344,7 +350,7 @@ extern "C" int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, in
     }
     const int chunks = colsum_chunks(M);
     const int rpc = (int)((M + chunks - 1) / chunks);
-    const dim3 grid((unsigned)((N / epv + 15) / 16), chunks);
+    const dim3 grid((unsigned)((N / epv + 63) / 64), chunks);
     if (dtype == UCFVIT_F32)
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)workspace, M, (int)N, ldx, rpc);
     else
