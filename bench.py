@@ -78,6 +78,22 @@ class GemmProfiler:
         return n, tot_ms, tot_flops
 
 
+def pmc_traffic(workload, dtype, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, profiles/r01_pmc_traffic_*.json) — counters cannot be read from inside the process; null if no matching profile."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("workload") == workload and d.get("dtype") == dtype and d.get("per_gpu_batch") == batch:
+                for k, v in d["kernels"].items():
+                    if k.startswith("gemm3"):
+                        return round(v["hbm_bytes_per_launch_corrected"])
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(wname, w, steps=3, batch=8):
     """reference training loop (train_class_simple.py:344-357) restated on CPU fp32: oracle, timed on the host cores"""
     from oracle import ucf_vit_ref as R
@@ -218,7 +234,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_mfma_kernel<%s> (all fwd/dgrad/wgrad launches of the timed region)" % args.dtype,
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None, "launches": n_g, "avg_launch_ms": round(g_ms / max(n_g, 1), 4),
+                         "traffic": pmc_traffic(args.workload, args.dtype, B), "launches": n_g, "avg_launch_ms": round(g_ms / max(n_g, 1), 4),
                          "avg_launch_gflop": round(g_flops / max(n_g, 1) / 1e9, 2),
                          "gemm_time_share_of_step": round(g_ms * 1e-3 / dt, 3),
                          "whole_step_tflops_per_gpu": round(step_tflops, 1), "whole_step_frac": round(step_tflops / peak, 4)},

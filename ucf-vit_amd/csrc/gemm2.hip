@@ -105,30 +105,62 @@ __device__ __forceinline__ void tile_origin(int t, int tiles_m, int tiles_n, int
     n0 = (band * BAND + in_band % band_w) * BN;
 }
 
-// PERSISTENT kernel: gridDim.x workgroups (<= resident capacity) walk the tile list round by round.  The first K-tile of the
-// NEXT output tile is DMA-prefetched during the last K-step of the current one, so neither the prologue latency nor the
+// XCD-blocked work schedule.  Hardware hands workgroup w to XCD w % 8 and every XCD has a private L2, so operand panels are
+// only shared between tiles that run on the SAME XCD at the same time.  The output tile grid of one K-slice is cut into compact
+// blocks of bm x bn tiles (<= 64 = the XCD's resident workgroups, 2 per CU); block-slice bs = block * splits + slice is processed
+// by XCD bs % 8 in round bs / 8, workgroup slot (w / 8) taking tile `slot` of the block.  A block touches bm + bn operand panels
+// instead of 2 * bm * bn, and no other XCD touches them during that round (measured before this schedule, wgrad at B=166:
+// FETCH_SIZE 2.7x the algorithmic bytes because each XCD walked 3 x 8 tiles of EVERY slice).
+struct Sched2 {
+    int bm, bn;        // block shape in tiles
+    int nbn;           // blocks along N
+    int nblocks;       // blocks per K-slice
+    int splits;        // K-slices
+    int k_per_split;   // contraction extent of a slice (multiple of BK2)
+};
+
+struct Work2 {
+    int m0, n0, k_begin, nk, klast, slice;
+};
+
+// first round >= r in which workgroup (xcd, slot) owns a tile; -1 when there is none
+__device__ __forceinline__ int sched2_locate(const Sched2& sc, int tiles_m, int tiles_n, int BM, int BN, int K, int xcd, int slot, int r,
+                                             Work2& w) {
+    const int total = sc.nblocks * sc.splits;
+    for (int bs = xcd + 8 * r; bs < total; bs += 8, ++r) {
+        const int block = bs / sc.splits;
+        const int bi = block / sc.nbn, bj = block - bi * sc.nbn;
+        const int rows = min(sc.bm, tiles_m - bi * sc.bm), cols = min(sc.bn, tiles_n - bj * sc.bn);
+        if (slot >= rows * cols) continue;
+        w.slice = bs - block * sc.splits;
+        w.m0 = (bi * sc.bm + slot / cols) * BM;
+        w.n0 = (bj * sc.bn + slot % cols) * BN;
+        w.k_begin = w.slice * sc.k_per_split;
+        const int k_end = min(K, w.k_begin + sc.k_per_split);
+        w.nk = (k_end - w.k_begin + BK2 - 1) / BK2;
+        w.klast = k_end - w.k_begin - (w.nk - 1) * BK2;      // valid contraction extent of the last K-tile (1..64)
+        return r;
+    }
+    return -1;
+}
+
+// PERSISTENT kernel: 8 x slots workgroups (<= resident capacity) walk their XCD's block-slices round by round.  The first K-tile
+// of the NEXT output tile is DMA-prefetched during the last K-step of the current one, so neither the prologue latency nor the
 // epilogue (LDS-staged, full-line stores) leaves the MFMA pipe idle for a whole HBM round trip.
 template <int LA, int LB, int BM, int BN, int WM, int WN, typename OutT>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C,
                                                              int M, int N, int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m,
-                                                             int tiles_n, int k_per_split) {
+                                                             int tiles_n, Sched2 sc) {
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int nwg = tiles_m * tiles_n;
-    const int G = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WN) * TM, wn = (wave % WN) * TN;
     const int g = lane >> 4, li = lane & 15;
-
-    const int k_begin = blockIdx.y * k_per_split;
-    const int k_end = min(K, k_begin + k_per_split);
-    const int nk = (k_end - k_begin + BK2 - 1) / BK2;
-    const int klast = k_end - k_begin - (nk - 1) * BK2;      // valid contraction extent of the last K-tile (1..64)
-    float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
 
     // epilogue staging geometry (wave-private LDS rows inside the just-consumed pipeline buffer)
     constexpr int PADW = TN + 4;                       // fp32 words per staged row
@@ -138,22 +170,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
     static_assert(NWAVES * 16 * PADW * 4 <= BUF, "epilogue staging must fit one pipeline buffer");
 
     int it = 0;        // running K-tile counter: K-tile `it` lives in pipeline buffer it & 1
-    int m0, n0;
-    {
-        const int first = min(G, nwg);
-        if ((int)blockIdx.x >= first) return;
-        tile_origin(xcd_remap(blockIdx.x, first), tiles_m, tiles_n, BM, BN, m0, n0);
-    }
-    issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin, M, smem, wave, lane, nk == 1 ? klast : BK2);
-    issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin, N, smem + A_BYTES, wave, lane, nk == 1 ? klast : BK2);
+    Work2 cur, nxt;
+    int sched_round = sched2_locate(sc, tiles_m, tiles_n, BM, BN, K, xcd, slot, 0, cur);
+    if (sched_round < 0) return;
+    issue_tile<LA, BM, NWAVES>(A, lda, cur.m0, cur.k_begin, M, smem, wave, lane, cur.nk == 1 ? cur.klast : BK2);
+    issue_tile<LB, BN, NWAVES>(B, ldb, cur.n0, cur.k_begin, N, smem + A_BYTES, wave, lane, cur.nk == 1 ? cur.klast : BK2);
 
     for (int round = 0;; ++round) {
         // next tile of this workgroup (if any)
-        int nm0 = 0, nn0 = 0;
-        const int next_base = (round + 1) * G;
-        const int next_cnt = min(G, nwg - next_base);
-        const bool has_next = (int)blockIdx.x < next_cnt;
-        if (has_next) tile_origin(next_base + xcd_remap(blockIdx.x, next_cnt), tiles_m, tiles_n, BM, BN, nm0, nn0);
+        const int next_round = sched2_locate(sc, tiles_m, tiles_n, BM, BN, K, xcd, slot, sched_round + 1, nxt);
+        const bool has_next = next_round >= 0;
+        const int m0 = cur.m0, n0 = cur.n0, k_begin = cur.k_begin, nk = cur.nk, klast = cur.klast;
+        float* slab = ep.slab ? ep.slab + (int64_t)cur.slice * M * N : nullptr;
 
         f32x4 acc[FM][FN];
 #pragma unroll
@@ -173,9 +201,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
                 issue_tile<LA, BM, NWAVES>(A, lda, m0, k_begin + (kt + 1) * BK2, M, nb, wave, lane, kr);
                 issue_tile<LB, BN, NWAVES>(B, ldb, n0, k_begin + (kt + 1) * BK2, N, nb + A_BYTES, wave, lane, kr);
             } else if (has_next) {
-                const int kr = nk == 1 ? klast : BK2;
-                issue_tile<LA, BM, NWAVES>(A, lda, nm0, k_begin, M, nb, wave, lane, kr);
-                issue_tile<LB, BN, NWAVES>(B, ldb, nn0, k_begin, N, nb + A_BYTES, wave, lane, kr);
+                const int kr = nxt.nk == 1 ? nxt.klast : BK2;
+                issue_tile<LA, BM, NWAVES>(A, lda, nxt.m0, nxt.k_begin, M, nb, wave, lane, kr);
+                issue_tile<LB, BN, NWAVES>(B, ldb, nxt.n0, nxt.k_begin, N, nb + A_BYTES, wave, lane, kr);
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -291,8 +319,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
         }
         if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
         if (!has_next) break;
-        m0 = nm0;
-        n0 = nn0;
+        cur = nxt;
+        sched_round = next_round;
     }
 }
 
@@ -703,14 +731,26 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
             static int target = 0;
             if (!target) {
                 const char* e = getenv("UCFVIT_GEMM_SPLIT_TARGET");
-                target = e ? atoi(e) : 512;
-                if (target < 1) target = 512;
+                target = e ? atoi(e) : 384;
+                if (target < 8) target = 384;
             }
-            int s = (int)(target / t128);                    // largest split that still fits ONE round of resident workgroups (2 per CU)
+            // split-K so that every XCD owns whole 8 x 8-tile blocks (64 resident workgroups = 2 per CU) of ONE K-slice and
+            // all 8 XCDs are busy in every round: nb64 * s block-slices must be a multiple of 8 (see Sched2)
+            const int64_t tm = (d->M + 127) / 128, tn = (d->N + 127) / 128;
+            const int nb64 = (int)(((tm + 7) / 8) * ((tn + 7) / 8));
+            int g8 = 8;
+            while (nb64 % g8) g8 >>= 1;                     // gcd(nb64, 8)
+            int s = 8 / g8;
+            if (nb64 * s > target / 8) s = 1;                // too many rounds of slab traffic: plain persistent walk
             const int kmax = (int)(ktiles_all / 8);          // at least 8 K-tiles per slice
             if (s > kmax) s = kmax;
-            if (s > 16) s = 16;
             if (s < 1) s = 1;
+            static int force_splits = -1;
+            if (force_splits < 0) {
+                const char* e = getenv("UCFVIT_GEMM_SPLITS");   // experiments only
+                force_splits = e ? atoi(e) : 0;
+            }
+            if (force_splits > 0) s = force_splits < kmax ? force_splits : (kmax > 0 ? kmax : 1);
             p->splits = s;
         }
     }
@@ -718,6 +758,35 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
     p->k_per_split = (int)(((ktiles + p->splits - 1) / p->splits) * BK2);
     p->splits = (int)((d->K + p->k_per_split - 1) / p->k_per_split);
     return true;
+}
+
+// block shape for the XCD-blocked schedule: `cap` = resident workgroups of one XCD (32 CUs x 1 or 2)
+inline Sched2 make_sched2(int tiles_m, int tiles_n, int splits, int k_per_split, int cap) {
+    const int64_t work = (int64_t)tiles_m * tiles_n * splits;
+    int T = (int)((work + 7) / 8);                        // tile-slices per XCD if everything fits one round
+    if (T > cap || splits > 1) T = cap;                   // split-K plans are made for full blocks (plan2)
+    if (T < 1) T = 1;
+    int bm = cap == 64 ? 8 : 4;
+    if (bm > tiles_m) bm = tiles_m;
+    if (bm > T) bm = T;
+    int bn = (T + bm - 1) / bm;
+    if (bn > tiles_n) {                                   // narrow problem: spend the rest of the block on rows
+        bn = tiles_n;
+        bm = (T + bn - 1) / bn;
+        if (bm > tiles_m) bm = tiles_m;
+    }
+    while (bm * bn > cap) {
+        if (bn > 1) --bn;
+        else --bm;
+    }
+    Sched2 sc;
+    sc.bm = bm;
+    sc.bn = bn;
+    sc.nbn = (tiles_n + bn - 1) / bn;
+    sc.nblocks = ((tiles_m + bm - 1) / bm) * sc.nbn;
+    sc.splits = splits;
+    sc.k_per_split = k_per_split;
+    return sc;
 }
 
 template <int LA, int LB, int BM, int BN, int WM, int WN, typename OutT>
@@ -736,13 +805,11 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
             done = true;
         }
     }
-    // persistent grid: one workgroup per CU for the 128-KiB-LDS tile, two for the 64-KiB one (split-K slices multiply the grid)
-    const int ntiles = tiles_m * tiles_n;
-    int cap = (BM == 256 ? 256 : 512) / p.splits;
-    if (cap < 1) cap = 1;
-    const int gx = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL(kern, dim3(gx, p.splits), dim3(WM * WN * 64), smem, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C,
-                       (int)d->M, (int)d->N, (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n, p.k_per_split);
+    // persistent grid: 8 XCDs x `slots` workgroups; one workgroup per CU for the 128-KiB-LDS tile, two for the 64-KiB one
+    const Sched2 sc = make_sched2(tiles_m, tiles_n, p.splits, p.k_per_split, BM == 256 ? 32 : 64);
+    const int gx = 8 * sc.bm * sc.bn;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(WM * WN * 64), smem, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C,
+                       (int)d->M, (int)d->N, (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n, sc);
     UCF_LAUNCH_CHECK("ucfvit_gemm(v2)");
     if (p.splits > 1) {
         const int64_t work = d->M * (d->N / 4);
