@@ -274,6 +274,33 @@ def test_gemm_v2_tiles_edges_epilogues(M, N, K):
     assert rel_err(dx.float(), (dy64 @ W64) * aux64.grad) < 1e-2
 
 
+@pytest.mark.parametrize("M", [512, 49152])
+def test_gemm_bf16_gelu_epilogue_accuracy(M):
+    """fused erf-GELU / GELU' epilogues of the bf16 GEMM (erfc by Abramowitz-Stegun 7.1.28, csrc/common.h) against torch's erf in
+    fp64.  Identity weights make the GEMM an exact copy, so only the activation math is compared; tolerance: one bf16 ulp
+    (2^-8 relative) + 2e-6 absolute.  M=512 runs the 128x128 kernel, M=49152 the 256x256 ping-pong kernel."""
+    from UCF_VIT._hip import ops
+    from UCF_VIT._hip.lib import ACT_GELU
+    D = 256
+    gen = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, D, generator=gen) * 3.0).bfloat16()
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 30.0, -30.0, 8.0, -8.0]).bfloat16()
+    eye = torch.eye(D).bfloat16().to(DEV)
+    xd = x.to(DEV)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.gelu(x64)
+    ref.sum().backward()
+    h = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    y = ops.linear_fwd(xd, eye, None, act=ACT_GELU, aux_out=h)
+    assert torch.equal(h.cpu(), x)
+    err = (y.cpu().double() - ref.detach()).abs()
+    assert bool((err <= ref.detach().abs() * 2.0 ** -8 + 2e-6).all()), float(err.max())
+    ones = torch.ones(M, D, dtype=torch.bfloat16, device=DEV)
+    dx = ops.linear_dgrad(ones, eye, act_grad_aux=xd)
+    err = (dx.cpu().double() - x64.grad).abs()
+    assert bool((err <= x64.grad.abs() * 2.0 ** -8 + 2e-6).all()), float(err.max())
+
+
 @pytest.mark.parametrize("Mtok,N,K", [(25216 // 8, 1024, 1024), (3200, 256, 384), (6400, 3072, 128), (3208, 512, 256), (4136, 1024, 4096), (3302, 1024, 512)])
 def test_gemm_v2_wgrad_splitk(Mtok, N, K):
     """weight gradient (KS x KS) with split-K partial sums: fp32 output, overwrite then accumulate"""

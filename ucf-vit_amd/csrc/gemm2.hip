@@ -92,6 +92,7 @@ struct Epi2 {
     float alpha;
     float* slab;       // split-K: fp32 partial matrices [splits][M][N] (ld = N); NULL when gridDim.y == 1
     unsigned long long* dbg;  // diagnostic stamps (UCFVIT_GEMM_DBG builds of the bench only); NULL in production
+    int warm;          // 1: touch the C-shaped epilogue input during the K loop (UCFVIT_GEMM_WARM=0 disables, experiments)
 };
 
 // logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
@@ -182,7 +183,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
         const bool has_next = next_round >= 0;
         const int m0 = cur.m0, n0 = cur.n0, k_begin = cur.k_begin, nk = cur.nk, klast = cur.klast;
         float* slab = ep.slab ? ep.slab + (int64_t)cur.slice * M * N : nullptr;
-
         f32x4 acc[FM][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -278,12 +278,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
                     }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+                    gelu_fast8(v);
                 } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
                     const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+                    float hf[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(h.get(r));
+                    for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
+                    gelu_grad_fast8(v, hf);
                 }
                 if (ep.residual) {
                     const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
@@ -547,12 +548,30 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #define PP_ISSUE_B(kt_) PP_ISSUE_ONE(LB, BN, Bb, ldb, offB, nBb, nldb, nn0, nN, A_BYTES, kt_)
 #define PP_ISSUE_A(kt_) PP_ISSUE_ONE(LA, BM, Ab, lda, offA, nAb, nlda, nm0, nM, 0, kt_)
 
+        const bf16* warm_base = nullptr;
+        int64_t warm_ld = 0;
+        if (sizeof(OutT) == 2 && !slab && ep.warm) {
+            if (ep.act == UCFVIT_ACT_GELU_GRAD) warm_base = ep.aux_in, warm_ld = ep.ldaux;
+            else if (ep.residual) warm_base = ep.residual, warm_ld = ep.ldr;
+        }
+        const int warm_k0 = nk > 16 ? nk - 16 : 0;          // the last 16 K-tiles each carry 1/16 of the touch
         // One program for both groups; G1 runs it one barrier interval behind G0 (extra barrier before / after the loop).
         if (grp == 1) PP_BARRIER();
 #pragma clang loop unroll(disable)
         for (int kt = 0; kt < nk; ++kt, ++it) {
             const char* bufA = smem + (it & 1) * BUF;
             const char* bufB = bufA + A_BYTES;
+            if (warm_base && kt >= warm_k0) {
+                // pull 1/16 of the tile's C-shaped epilogue input (gelu' pre-activation / residual) into L2 / the memory-side cache
+                // while the MFMAs run, so the epilogue's loads do not pay HBM latency with only a few KB in flight: one 1-KiB DMA
+                // piece per wave per K-tile into a dump area (no result VGPRs; issued before the B pieces, so it is older than
+                // everything the counted waits below leave in flight)
+                const int row = (wave * 16 + (kt - warm_k0)) * 2 + (lane >> 5);
+                int m = m0 + row, n = n0 + (lane & 31) * 8;
+                m = m < M ? m : M - 1;
+                n = n < N ? n : N - 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)(warm_base + (int64_t)m * warm_ld + n), (lptr_t)(smem + 2 * BUF + wave * 1024), 16, 0, 0);
+            }
             PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) + fragment reads
             PP_READ(bufA, bufB, 0);
             PP_BARRIER();
@@ -575,6 +594,40 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #undef PP_ISSUE_B
 
         // ---- epilogue (same as gemm2_kernel): staging area = the pipeline buffer of the K-tile just consumed ----------
+        // The one extra C-shaped input of a bf16 epilogue (gelu' pre-activation or residual) is fetched for the whole wave tile
+        // BEFORE the strips are staged: 16 loads in flight instead of one exposed HBM round trip per strip (measured in-step at
+        // B=166: residual / gelu' epilogues 26-30 us per tile against 8-10 us for the plain one).
+        constexpr int NPASS = 16 / RPI;
+        constexpr int PD = 2;                       // strips fetched up front; each finished strip frees 16 accumulator VGPRs = room for
+        Vec16<bf16> pre[FM][NPASS];                 // two more (all FM strips up front would spill inside the K loop)
+        int pre_kind = 0;
+        const bf16* pre_base = nullptr;
+        int64_t pre_ldv = 0;
+#define PRE_LOAD(i_)                                                                                                   \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                                         \
+            const int m_ = m0 + wm + 16 * (i_) + ps * RPI + prow;                                                      \
+            const int n_ = n0 + wn + pcol;                                                                             \
+            if (m_ < M && n_ < N) pre[i_][ps] = *reinterpret_cast<const Vec16<bf16>*>(pre_base + (int64_t)m_ * pre_ldv + n_); \
+        }                                                                                                              \
+    } while (0)
+        constexpr bool PREFETCH = sizeof(OutT) == 2 && LA == 0 && LB == 0;   // the KS instantiations have no registers to spare
+        if constexpr (PREFETCH) {
+            const bf16* pre_ptr = nullptr;
+            int64_t pre_ld = 0;
+            if (!slab) {
+                if (ep.act == UCFVIT_ACT_GELU_GRAD) {
+                    pre_ptr = ep.aux_in, pre_ld = ep.ldaux, pre_kind = 1;
+                } else if (ep.residual) {
+                    pre_ptr = ep.residual, pre_ld = ep.ldr, pre_kind = 2;
+                }
+            }
+            pre_base = pre_ptr, pre_ldv = pre_ld;
+            if (pre_kind) {
+#pragma unroll
+                for (int i = 0; i < PD; ++i) PRE_LOAD(i);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -625,15 +678,20 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = o.get(r);
                     }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+                    gelu_fast8(v);
                 } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
-                    const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+                    Vec16<bf16> h;
+                    if (pre_kind == 1) h = pre[i][rr / RPI];
+                    else h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+                    float hf[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] *= gelu_grad_f(h.get(r));
+                    for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
+                    gelu_grad_fast8(v, hf);
                 }
                 if (ep.residual) {
-                    const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
+                    Vec16<bf16> rv;
+                    if (pre_kind == 2) rv = pre[i][rr / RPI];
+                    else rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
                 }
@@ -663,7 +721,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
                     *reinterpret_cast<f32x4*>(cp + 4) = o1;
                 }
             }
+            if constexpr (PREFETCH) {
+                if (pre_kind) {
+                    if (PD + 2 * i < FM) PRE_LOAD(PD + 2 * i);
+                    if (PD + 2 * i + 1 < FM) PRE_LOAD(PD + 2 * i + 1);
+                }
+            }
         }
+#undef PRE_LOAD
         if (!has_next) break;
         m0 = nm0;
         n0 = nn0;
@@ -824,7 +889,7 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
 
 template <int LA, int LB, typename OutT>
 int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
-    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128;
+    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 8192;   // pipeline buffers + the cache-warming dump area
     auto kern = gemm3_kernel<LA, LB, OutT>;
     static bool done = false;
     if (!done) {
@@ -932,6 +997,14 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     ep.accumulate = d->accumulate;
     ep.alpha = d->alpha;
     ep.slab = nullptr;
+    {
+        static int warm = -1;
+        if (warm < 0) {
+            const char* e = getenv("UCFVIT_GEMM_WARM");
+            warm = (e && e[0] == '0') ? 0 : 1;
+        }
+        ep.warm = warm;
+    }
     {
         const char* e = getenv("UCFVIT_GEMM_DBG");
         ep.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
