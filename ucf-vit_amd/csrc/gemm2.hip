@@ -434,7 +434,14 @@ struct Groups3 {
     int n, total_tiles;
 };
 
-template <int LA, int LB, typename OutT>
+// Epilogue specialisations of the forward / data-gradient GEMM (KC x KC, bf16 out, one problem, no split-K, no accumulate).  The
+// generic epilogue decides everything at run time; under the accumulators' register pressure that code spills, and hipcc, which
+// cannot see the asm waits that retire the LDS-DMA, drains vmcnt(0) — loads AND the strips' stores, which share the counter — at
+// every use of a loaded value (124 drains per tile).  A specialised epilogue is straight-line: its one C-shaped input is fetched
+// PD strips ahead with counted waits, its stores are never waited for.
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RESIDUAL = 2, EPI_GELU = 3, EPI_GELU_GRAD = 4 };
+
+template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, int k_per_split) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
@@ -593,46 +600,105 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #undef PP_ISSUE_A
 #undef PP_ISSUE_B
 
-        // ---- epilogue (same as gemm2_kernel): staging area = the pipeline buffer of the K-tile just consumed ----------
-        // The one extra C-shaped input of a bf16 epilogue (gelu' pre-activation or residual) is fetched for the whole wave tile
-        // BEFORE the strips are staged: 16 loads in flight instead of one exposed HBM round trip per strip (measured in-step at
-        // B=166: residual / gelu' epilogues 26-30 us per tile against 8-10 us for the plain one).
-        constexpr int NPASS = 16 / RPI;
-        constexpr int PD = 2;                       // strips fetched up front; each finished strip frees 16 accumulator VGPRs = room for
-        Vec16<bf16> pre[FM][NPASS];                 // two more (all FM strips up front would spill inside the K loop)
-        int pre_kind = 0;
-        const bf16* pre_base = nullptr;
-        int64_t pre_ldv = 0;
-#define PRE_LOAD(i_)                                                                                                   \
-    do {                                                                                                               \
-        _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                                         \
-            const int m_ = m0 + wm + 16 * (i_) + ps * RPI + prow;                                                      \
-            const int n_ = n0 + wn + pcol;                                                                             \
-            if (m_ < M && n_ < N) pre[i_][ps] = *reinterpret_cast<const Vec16<bf16>*>(pre_base + (int64_t)m_ * pre_ldv + n_); \
-        }                                                                                                              \
-    } while (0)
-        constexpr bool PREFETCH = sizeof(OutT) == 2 && LA == 0 && LB == 0;   // the KS instantiations have no registers to spare
-        if constexpr (PREFETCH) {
-            const bf16* pre_ptr = nullptr;
-            int64_t pre_ld = 0;
-            if (!slab) {
-                if (ep.act == UCFVIT_ACT_GELU_GRAD) {
-                    pre_ptr = ep.aux_in, pre_ld = ep.ldaux, pre_kind = 1;
-                } else if (ep.residual) {
-                    pre_ptr = ep.residual, pre_ld = ep.ldr, pre_kind = 2;
+        // ---- epilogue: staging area = the pipeline buffer of the K-tile just consumed ------------------------------------------
+        float* stage = reinterpret_cast<float*>(smem + ((it - 1) & 1) * BUF) + wave * (16 * PADW);
+        if constexpr (EPI != EPI_GENERIC) {
+            static_assert(sizeof(OutT) == 2, "specialised epilogues write bf16");
+            constexpr int NPASS = 16 / RPI;
+            constexpr bool HAS_IN = EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD;
+            constexpr int PD = 3;                      // strips of the C-shaped input in flight ahead of their use
+            // every DMA piece has been waited for by the asm waits above; a wait hipcc can see resets its bookkeeping (free: the
+            // queue is empty), so the loads below get counted waits instead of vmcnt(0)
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) expcnt(7) lgkmcnt(15)
+            Vec4<bf16> bias_v[FN];
+            const bool has_bias = ep.bias != nullptr;
+            if (has_bias) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + wn + 16 * j + 4 * g;
+                    bias_v[j] = *reinterpret_cast<const Vec4<bf16>*>(ep.bias + (n < N ? n : 0));
                 }
             }
-            pre_base = pre_ptr, pre_ldv = pre_ld;
-            if (pre_kind) {
+            const bf16* in_base = EPI == EPI_RESIDUAL ? ep.residual : ep.aux_in;
+            const int64_t in_ld = EPI == EPI_RESIDUAL ? ep.ldr : ep.ldaux;
+            Vec16<bf16> pre[FM][NPASS];
+            const int ncl = min(n0 + wn + pcol, N - 8);                 // clamped: the loads are unconditional, the stores masked
+#define EPI_LOAD(i_)                                                                                                   \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                                         \
+            const int m_ = min(m0 + wm + 16 * (i_) + ps * RPI + prow, M - 1);                                          \
+            pre[i_][ps] = *reinterpret_cast<const Vec16<bf16>*>(in_base + (int64_t)m_ * in_ld + ncl);                  \
+        }                                                                                                              \
+    } while (0)
+            if constexpr (HAS_IN) {
 #pragma unroll
-                for (int i = 0; i < PD; ++i) PRE_LOAD(i);
+                for (int i = 0; i < PD; ++i) EPI_LOAD(i);
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    f32x4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= ep.alpha;
+                    if (has_bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += bias_v[j].get(r);
+                    }
+                    *reinterpret_cast<f32x4*>(stage + li * PADW + 16 * j + 4 * g) = v;
+                }
+                if constexpr (HAS_IN) {
+                    if (i + PD < FM) EPI_LOAD(i + PD);      // ahead of this strip's stores: its wait will not include them
+                }
+#pragma unroll
+                for (int rr = 0; rr < 16; rr += RPI) {
+                    const int row = rr + prow;
+                    const int m = m0 + wm + 16 * i + row;
+                    const int n = n0 + wn + pcol;
+                    const bool inside = m < M && n < N;
+                    float v[8];
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * PADW + pcol + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = lo[r];
+                        v[4 + r] = hi[r];
+                    }
+                    if constexpr (EPI == EPI_GELU) {
+                        if (ep.aux_out) {
+                            Vec16<bf16> o;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+                            if (inside) *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
+                        }
+                        gelu_fast8(v);
+                    } else if constexpr (EPI == EPI_GELU_GRAD) {
+                        float hf[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) hf[r] = pre[i][rr / RPI].get(r);
+                        gelu_grad_fast8(v, hf);
+                    } else if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += pre[i][rr / RPI].get(r);
+                    }
+                    Vec16<bf16> o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+                    if (inside) *reinterpret_cast<Vec16<bf16>*>(C + (int64_t)m * ldc + n) = o;
+                }
+            }
+#undef EPI_LOAD
+        } else {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        float* stage = reinterpret_cast<float*>(smem + ((it - 1) & 1) * BUF) + wave * (16 * PADW);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -680,18 +746,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
                     }
                     gelu_fast8(v);
                 } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
-                    Vec16<bf16> h;
-                    if (pre_kind == 1) h = pre[i][rr / RPI];
-                    else h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+                    const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
                     float hf[8];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
                     gelu_grad_fast8(v, hf);
                 }
                 if (ep.residual) {
-                    Vec16<bf16> rv;
-                    if (pre_kind == 2) rv = pre[i][rr / RPI];
-                    else rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
+                    const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
                 }
@@ -721,14 +783,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
                     *reinterpret_cast<f32x4*>(cp + 4) = o1;
                 }
             }
-            if constexpr (PREFETCH) {
-                if (pre_kind) {
-                    if (PD + 2 * i < FM) PRE_LOAD(PD + 2 * i);
-                    if (PD + 2 * i + 1 < FM) PRE_LOAD(PD + 2 * i + 1);
-                }
-            }
         }
-#undef PRE_LOAD
+        }   // EPI_GENERIC
         if (!has_next) break;
         m0 = nm0;
         n0 = nn0;
@@ -887,10 +943,10 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
     return UCFVIT_OK;
 }
 
-template <int LA, int LB, typename OutT>
+template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC>
 int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
     constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 8192;   // pipeline buffers + the cache-warming dump area
-    auto kern = gemm3_kernel<LA, LB, OutT>;
+    auto kern = gemm3_kernel<LA, LB, OutT, EPI>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -930,6 +986,25 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
     fill_problem(gt.p[0], d, 0);
     gt.n = 1;
     gt.total_tiles = gt.p[0].tiles_m * gt.p[0].tiles_n;
+    if constexpr (LA == UCFVIT_LAYOUT_KC && LB == UCFVIT_LAYOUT_KC && sizeof(OutT) == 2) {
+        // straight-line epilogues for the shapes of the training step (see EPI_* above); everything else is generic
+        static int generic_only = -1;
+        if (generic_only < 0) {
+            const char* e = getenv("UCFVIT_GEMM_GENERIC_EPI");   // experiments / A-B runs
+            generic_only = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (!generic_only && p.splits == 1 && !ep.slab && !d->accumulate && d->N >= 8) {
+            const int K_ = (int)d->K;
+            if (ep.act == UCFVIT_ACT_NONE && !ep.residual && !ep.aux_out)
+                return launch3g<LA, LB, OutT, EPI_PLAIN>(gt, K_, ep, 1, p.k_per_split, s);
+            if (ep.act == UCFVIT_ACT_NONE && ep.residual && !ep.aux_out)
+                return launch3g<LA, LB, OutT, EPI_RESIDUAL>(gt, K_, ep, 1, p.k_per_split, s);
+            if (ep.act == UCFVIT_ACT_GELU && !ep.residual)
+                return launch3g<LA, LB, OutT, EPI_GELU>(gt, K_, ep, 1, p.k_per_split, s);
+            if (ep.act == UCFVIT_ACT_GELU_GRAD && !ep.residual && !ep.aux_out)
+                return launch3g<LA, LB, OutT, EPI_GELU_GRAD>(gt, K_, ep, 1, p.k_per_split, s);
+        }
+    }
     return launch3g<LA, LB, OutT>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
 }
 
