@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 2
+#define UCFVIT_ABI_VERSION 3
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -60,6 +60,9 @@ const char* ucfvit_last_error(void);
  * Epilogue, in order:  v = alpha*acc ; v += bias[n] ; act ; v += residual[m][n] ; v += C_old (accumulate) ; store.
  *   act = UCFVIT_ACT_GELU      : if aux_out, aux_out[m][n] = v (pre-activation, saved for backward); v = gelu_erf(v)
  *   act = UCFVIT_ACT_GELU_GRAD : v *= gelu_erf'(aux_in[m][n])   (dgrad through the activation; aux_in = saved pre-activation)
+ *   act = UCFVIT_ACT_GELU_SAVE_DERIV / UCFVIT_ACT_MUL_AUX : the same pair with the derivative evaluated once, in the forward
+ *         epilogue where gelu shares its erfc, and saved in place of the pre-activation; the backward epilogue is a multiply.
+ *         The bf16 training path uses this pair (one bf16 rounding of gelu' instead of one of its argument); fp32 keeps the first.
  * `dtype` = type of A and B (and bias/residual/aux); `out_dtype` = type of C (UCFVIT_F32 for parameter gradients).
  * ------------------------------------------------------------------------------------------------------ */
 #define UCFVIT_LAYOUT_KC 0
@@ -67,6 +70,8 @@ const char* ucfvit_last_error(void);
 #define UCFVIT_ACT_NONE 0
 #define UCFVIT_ACT_GELU 1
 #define UCFVIT_ACT_GELU_GRAD 2
+#define UCFVIT_ACT_GELU_SAVE_DERIV 3 /* forward:  aux_out[m][n] = gelu_erf'(v) (required); v = gelu_erf(v) */
+#define UCFVIT_ACT_MUL_AUX 4         /* backward: v *= aux_in[m][n]   (aux_in = the derivative saved by ACT_GELU_SAVE_DERIV) */
 
 typedef struct ucfvit_gemm_desc {
     const void* A;

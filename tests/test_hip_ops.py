@@ -299,6 +299,17 @@ def test_gemm_bf16_gelu_epilogue_accuracy(M):
     dx = ops.linear_dgrad(ones, eye, act_grad_aux=xd)
     err = (dx.cpu().double() - x64.grad).abs()
     assert bool((err <= x64.grad.abs() * 2.0 ** -8 + 2e-6).all()), float(err.max())
+    # the derivative-saving pair the bf16 MLP uses: forward stores gelu'(pre-activation), backward multiplies by it
+    from UCF_VIT._hip.lib import ACT_GELU_SAVE_DERIV
+    gd = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    y2 = ops.linear_fwd(xd, eye, None, act=ACT_GELU_SAVE_DERIV, aux_out=gd)
+    err = (y2.cpu().double() - ref.detach()).abs()
+    assert bool((err <= ref.detach().abs() * 2.0 ** -8 + 2e-6).all()), float(err.max())
+    err = (gd.cpu().double() - x64.grad).abs()
+    assert bool((err <= x64.grad.abs() * 2.0 ** -8 + 2e-6).all()), float(err.max())
+    two = torch.full((M, D), 2.0, dtype=torch.bfloat16, device=DEV)
+    dx2 = ops.linear_dgrad_t(two, eye, act_grad_aux=gd, aux_is_deriv=True)
+    assert torch.equal(dx2.float(), gd.float() * 2.0)
 
 
 @pytest.mark.parametrize("Mtok,N,K", [(25216 // 8, 1024, 1024), (3200, 256, 384), (6400, 3072, 128), (3208, 512, 256), (4136, 1024, 4096), (3302, 1024, 512)])

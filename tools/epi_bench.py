@@ -8,7 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ucf-vit_amd"))
 from UCF_VIT._hip import ops  # noqa: E402
-from UCF_VIT._hip.lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, LAYOUT_KC  # noqa: E402
+from UCF_VIT._hip.lib import ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX, ACT_NONE, LAYOUT_KC  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 166
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -58,4 +58,6 @@ run("fc1   bias+gelu", 4096, 1024, bias=True, act=ACT_GELU)
 run("fc1   bias+gelu+aux_out", 4096, 1024, bias=True, act=ACT_GELU, aux_out=True)
 run("fc2dg plain", 4096, 1024)
 run("fc2dg gelu_grad(aux_in)", 4096, 1024, act=ACT_GELU_GRAD, aux_in=True)
+run("fc1   bias+gelu+save deriv", 4096, 1024, bias=True, act=ACT_GELU_SAVE_DERIV, aux_out=True)
+run("fc2dg mul_aux(aux_in)", 4096, 1024, act=ACT_MUL_AUX, aux_in=True)
 run("qkv   bias", 3072, 1024, bias=True)

@@ -7,10 +7,12 @@ Block:236-239) and src/UCF_VIT/simple/arch.py (_pos_embed:367-393, random_maskin
 Parameter gradients are written by the kernels straight into the flat fp32 gradient buffer of the model's
 HipParamStore when there is one (see params.py); the view is handed to autograd so hooks (e.g. a DDP reducer) still fire.
 """
+import os
+
 import torch
 
 from . import ops
-from .lib import ACT_GELU, ACT_NONE
+from .lib import ACT_GELU, ACT_GELU_SAVE_DERIV, ACT_NONE
 from .params import compute_param, compute_param_t, grad_target
 
 
@@ -87,12 +89,22 @@ def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None):
     return dx, (None if aw else dg), (None if ab else db)
 
 
-def _dgrad(dy2, p_w, w, aux=None):
-    """dx = dy·W (optionally x gelu'(aux)); uses the transposed weight shadow when the flat store keeps one"""
+def _dgrad(dy2, p_w, w, aux=None, aux_is_deriv=False):
+    """dx = dy·W (optionally x gelu'(aux), or x aux when aux already is the derivative); uses the transposed weight shadow
+    when the flat store keeps one"""
     wT = compute_param_t(p_w, dy2.dtype)
     if wT is not None:
-        return ops.linear_dgrad_t(dy2, wT, act_grad_aux=aux)
-    return ops.linear_dgrad(dy2, w, act_grad_aux=aux)
+        return ops.linear_dgrad_t(dy2, wT, act_grad_aux=aux, aux_is_deriv=aux_is_deriv)
+    return ops.linear_dgrad(dy2, w, act_grad_aux=aux, aux_is_deriv=aux_is_deriv)
+
+
+_GELU_SAVE_DERIV = os.environ.get("UCFVIT_GELU_SAVE_DERIV", "1") != "0"     # A/B switch
+
+
+def _saves_gelu_deriv(dtype):
+    """bf16: the fc1 epilogue evaluates gelu' next to gelu (shared erfc) and saves it instead of the pre-activation, so the fc2
+    data-gradient epilogue is a multiply; fp32 keeps the pre-activation (one formulation with the oracle, parity 1e-6)"""
+    return dtype == torch.bfloat16 and _GELU_SAVE_DERIV
 
 
 class TP:
@@ -159,7 +171,8 @@ def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_p
 
 def _mlp_fwd(x2, w1, b1, w2, b2, residual, tp=None):
     h = torch.empty((x2.shape[0], w1.shape[0]), dtype=x2.dtype, device=x2.device)
-    a = ops.linear_fwd(x2, w1, b1, act=ACT_GELU, aux_out=h)            # K7: fc1 GEMM + bias + erf-GELU (pre-activation kept)
+    act = ACT_GELU_SAVE_DERIV if _saves_gelu_deriv(x2.dtype) else ACT_GELU
+    a = ops.linear_fwd(x2, w1, b1, act=act, aux_out=h)                 # K7: fc1 GEMM + bias + erf-GELU (h: pre-activation, or gelu' of it)
     if tp and tp.rank != 0:
         residual = None
     y = ops.linear_fwd(a, w2, b2, residual=residual)                   # K7: fc2 GEMM + bias (+ residual)
@@ -172,7 +185,7 @@ def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=
     h, a = saved
     g_w2 = _wgrad(p_w2, dy2, a, wq) if needs[2] else None
     g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
-    dh = _dgrad(dy2, p_w2, w2, aux=h)                                  # dgrad fused with gelu'(h)
+    dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype))   # dgrad fused with gelu'(pre-activation)
     g_w1 = _wgrad(p_w1, dh, x2, wq) if needs[0] else None
     g_b1 = _bgrad(p_b1, dh) if (p_b1 is not None and needs[1]) else None
     dx = _dgrad(dh, p_w1, w1)

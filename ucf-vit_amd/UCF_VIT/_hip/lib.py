@@ -9,8 +9,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
-ABI_VERSION = 2
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
+ABI_VERSION = 3
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libucfvit_hip.so")

@@ -7,7 +7,7 @@ import math
 import torch
 
 from . import lib as _l
-from .lib import ACT_GELU, ACT_GELU_GRAD, ACT_NONE, BF16, F32, LAYOUT_KC, LAYOUT_KS
+from .lib import ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX, ACT_NONE, BF16, F32, LAYOUT_KC, LAYOUT_KS
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
@@ -115,12 +115,18 @@ def linear_fwd(x2, w, b=None, act=ACT_NONE, residual=None, aux_out=None, out=Non
                 aux_out=aux_out)
 
 
-def linear_dgrad(dy2, w, act_grad_aux=None, out=None):
-    """dx[M,K] = dy2[M,N]·w[N,K]  (optionally times gelu'(aux) for the fc1 pre-activation)"""
+def _dgrad_act(act_grad_aux, aux_is_deriv):
+    if act_grad_aux is None:
+        return ACT_NONE
+    return ACT_MUL_AUX if aux_is_deriv else ACT_GELU_GRAD
+
+
+def linear_dgrad(dy2, w, act_grad_aux=None, out=None, aux_is_deriv=False):
+    """dx[M,K] = dy2[M,N]·w[N,K], optionally times gelu'(aux) (aux = the fc1 pre-activation) or times aux itself
+    (aux_is_deriv: aux = gelu' saved by the forward epilogue, ACT_GELU_SAVE_DERIV)"""
     M, N = dy2.shape
     K = w.shape[1]
-    return gemm(dy2, w, M, K, N, LAYOUT_KC, LAYOUT_KS, out=out, act=ACT_GELU_GRAD if act_grad_aux is not None else ACT_NONE,
-                aux_in=act_grad_aux)
+    return gemm(dy2, w, M, K, N, LAYOUT_KC, LAYOUT_KS, out=out, act=_dgrad_act(act_grad_aux, aux_is_deriv), aux_in=act_grad_aux)
 
 
 def linear_wgrad(dy2, x2, out=None, accumulate=False):
@@ -353,9 +359,8 @@ def transpose_batched(src_flat, dst_flat, table, n_mats, total_tiles):
              "ucfvit_transpose_batched")
 
 
-def linear_dgrad_t(dy2, wT, act_grad_aux=None, out=None):
+def linear_dgrad_t(dy2, wT, act_grad_aux=None, out=None, aux_is_deriv=False):
     """dx[M,K] = dy2[M,N]·W with W given TRANSPOSED (wT [K,N]): both operands contraction-contiguous (fast path)"""
     M, N = dy2.shape
     K = wT.shape[0]
-    return gemm(dy2, wT, M, K, N, LAYOUT_KC, LAYOUT_KC, out=out, act=ACT_GELU_GRAD if act_grad_aux is not None else ACT_NONE,
-                aux_in=act_grad_aux)
+    return gemm(dy2, wT, M, K, N, LAYOUT_KC, LAYOUT_KC, out=out, act=_dgrad_act(act_grad_aux, aux_is_deriv), aux_in=act_grad_aux)

@@ -153,6 +153,24 @@ __device__ __forceinline__ void gelu_grad_fast8(float* v, const float* h) {
     }
 }
 
+// v[0..7] = gelu(v[0..7]) and d[0..7] = gelu'(v[0..7]) from one erfc evaluation
+__device__ __forceinline__ void gelu_and_grad_fast8(float* v, float* d) {
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        const f32x2 x = {v[r], v[r + 1]};
+        const f32x2 cdf = norm_cdf_fast2(x);
+        const f32x2 e = x * x * -0.72134752044448170368f;
+        f32x2 pdf;
+        pdf[0] = 0.39894228040143267794f * __builtin_amdgcn_exp2f(e[0]);
+        pdf[1] = 0.39894228040143267794f * __builtin_amdgcn_exp2f(e[1]);
+        const f32x2 y = x * cdf, gd = cdf + x * pdf;
+        v[r] = y[0];
+        v[r + 1] = y[1];
+        d[r] = gd[0];
+        d[r + 1] = gd[1];
+    }
+}
+
 // XCD-aware bijective block remap: blocks b and b+8 share an XCD (observed round-robin), so give each
 // XCD label a contiguous chunk of the logical tile order (neighbouring tiles share operand panels -> L2 hits).
 // Speed only, never correctness.

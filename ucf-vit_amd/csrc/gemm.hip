@@ -239,6 +239,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_mfma_kernel(const T* __restrict
                 Vec4<T> h = *reinterpret_cast<const Vec4<T>*>(auxi + (int64_t)m * ep.ldaux + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(h.get(r));
+            } else if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV) {
+                Vec4<T> o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o.set(r, gelu_grad_f(v[r]));
+                    v[r] = gelu_f(v[r]);
+                }
+                *reinterpret_cast<Vec4<T>*>(auxo + (int64_t)m * ep.ldaux + n) = o;
+            } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
+                Vec4<T> h = *reinterpret_cast<const Vec4<T>*>(auxi + (int64_t)m * ep.ldaux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= h.get(r);
             }
             if (res) {
                 Vec4<T> rr = *reinterpret_cast<const Vec4<T>*>(res + (int64_t)m * ep.ldr + n);
@@ -283,6 +295,11 @@ __global__ void gemm_scalar_kernel(const T* __restrict__ A, const T* __restrict_
         v = gelu_f(v);
     } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
         v *= gelu_grad_f(to_f32<T>(((const T*)ep.aux_in)[m * ep.ldaux + n]));
+    } else if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV) {
+        ((T*)ep.aux_out)[m * ep.ldaux + n] = from_f32<T>(gelu_grad_f(v));
+        v = gelu_f(v);
+    } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
+        v *= to_f32<T>(((const T*)ep.aux_in)[m * ep.ldaux + n]);
     }
     if (ep.residual) v += to_f32<T>(((const T*)ep.residual)[m * ep.ldr + n]);
     OutT* cp = C + m * ep.ldc + n;
@@ -350,8 +367,9 @@ extern "C" int ucfvit_gemm(const ucfvit_gemm_desc* d, void* stream) {
     UCF_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "ucfvit_gemm: negative size");
     UCF_CHECK_ARG(d->a_layout == 0 || d->a_layout == 1, "ucfvit_gemm: bad a_layout %d", d->a_layout);
     UCF_CHECK_ARG(d->b_layout == 0 || d->b_layout == 1, "ucfvit_gemm: bad b_layout %d", d->b_layout);
-    UCF_CHECK_ARG(d->act >= 0 && d->act <= 2, "ucfvit_gemm: bad act %d", d->act);
-    UCF_CHECK_ARG(d->act != UCFVIT_ACT_GELU_GRAD || d->aux_in, "ucfvit_gemm: ACT_GELU_GRAD needs aux_in");
+    UCF_CHECK_ARG(d->act >= 0 && d->act <= 4, "ucfvit_gemm: bad act %d", d->act);
+    UCF_CHECK_ARG((d->act != UCFVIT_ACT_GELU_GRAD && d->act != UCFVIT_ACT_MUL_AUX) || d->aux_in, "ucfvit_gemm: act %d needs aux_in", d->act);
+    UCF_CHECK_ARG(d->act != UCFVIT_ACT_GELU_SAVE_DERIV || d->aux_out, "ucfvit_gemm: ACT_GELU_SAVE_DERIV needs aux_out");
     UCF_CHECK_ARG(d->lda >= ((d->a_layout == 0) ? d->K : d->M), "ucfvit_gemm: lda too small");
     UCF_CHECK_ARG(d->ldb >= ((d->b_layout == 0) ? d->K : d->N), "ucfvit_gemm: ldb too small");
     UCF_CHECK_ARG(d->ldc >= d->N, "ucfvit_gemm: ldc too small");

@@ -285,6 +285,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
 #pragma unroll
                     for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
                     gelu_grad_fast8(v, hf);
+                } else if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV) {
+                    float df[8];
+                    gelu_and_grad_fast8(v, df);
+                    Vec16<bf16> o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o.set(r, df[r]);
+                    *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
+                    const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= h.get(r);
                 }
                 if (ep.residual) {
                     const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
@@ -439,7 +450,7 @@ struct Groups3 {
 // cannot see the asm waits that retire the LDS-DMA, drains vmcnt(0) — loads AND the strips' stores, which share the counter — at
 // every use of a loaded value (124 drains per tile).  A specialised epilogue is straight-line: its one C-shaped input is fetched
 // PD strips ahead with counted waits, its stores are never waited for.
-enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RESIDUAL = 2, EPI_GELU = 3, EPI_GELU_GRAD = 4 };
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RESIDUAL = 2, EPI_GELU = 3, EPI_GELU_GRAD = 4, EPI_GELU_SAVE_DERIV = 5, EPI_MUL_AUX = 6 };
 
 template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, int k_per_split) {
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
         const bf16* warm_base = nullptr;
         int64_t warm_ld = 0;
         if (sizeof(OutT) == 2 && !slab && ep.warm) {
-            if (ep.act == UCFVIT_ACT_GELU_GRAD) warm_base = ep.aux_in, warm_ld = ep.ldaux;
+            if (ep.act == UCFVIT_ACT_GELU_GRAD || ep.act == UCFVIT_ACT_MUL_AUX) warm_base = ep.aux_in, warm_ld = ep.ldaux;
             else if (ep.residual) warm_base = ep.residual, warm_ld = ep.ldr;
         }
         const int warm_k0 = nk > 16 ? nk - 16 : 0;          // the last 16 K-tiles each carry 1/16 of the touch
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
         if constexpr (EPI != EPI_GENERIC) {
             static_assert(sizeof(OutT) == 2, "specialised epilogues write bf16");
             constexpr int NPASS = 16 / RPI;
-            constexpr bool HAS_IN = EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD;
+            constexpr bool HAS_IN = EPI == EPI_RESIDUAL || EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX;
             constexpr int PD = 3;                      // strips of the C-shaped input in flight ahead of their use
             // every DMA piece has been waited for by the asm waits above; a wait hipcc can see resets its bookkeeping (free: the
             // queue is empty), so the loads below get counted waits instead of vmcnt(0)
@@ -678,11 +689,21 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
                             for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
                         }
                         gelu_fast8(v);
+                    } else if constexpr (EPI == EPI_GELU_SAVE_DERIV) {
+                        float df[8];
+                        gelu_and_grad_fast8(v, df);
+                        Vec16<bf16> o;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o.set(r, df[r]);
+                        if (inside) *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
                     } else if constexpr (EPI == EPI_GELU_GRAD) {
                         float hf[8];
 #pragma unroll
                         for (int r = 0; r < 8; ++r) hf[r] = pre[i][rr / RPI].get(r);
                         gelu_grad_fast8(v, hf);
+                    } else if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= pre[i][rr / RPI].get(r);
                     } else if constexpr (EPI == EPI_RESIDUAL) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += pre[i][rr / RPI].get(r);
@@ -751,6 +772,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
                     gelu_grad_fast8(v, hf);
+                } else if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV) {
+                    float df[8];
+                    gelu_and_grad_fast8(v, df);
+                    Vec16<bf16> o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o.set(r, df[r]);
+                    *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
+                    const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= h.get(r);
                 }
                 if (ep.residual) {
                     const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
@@ -1003,6 +1035,10 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
                 return launch3g<LA, LB, OutT, EPI_GELU>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_GELU_GRAD && !ep.residual && !ep.aux_out)
                 return launch3g<LA, LB, OutT, EPI_GELU_GRAD>(gt, K_, ep, 1, p.k_per_split, s);
+            if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV && !ep.residual)
+                return launch3g<LA, LB, OutT, EPI_GELU_SAVE_DERIV>(gt, K_, ep, 1, p.k_per_split, s);
+            if (ep.act == UCFVIT_ACT_MUL_AUX && !ep.residual && !ep.aux_out)
+                return launch3g<LA, LB, OutT, EPI_MUL_AUX>(gt, K_, ep, 1, p.k_per_split, s);
         }
     }
     return launch3g<LA, LB, OutT>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
