@@ -82,6 +82,25 @@ __device__ __forceinline__ bf16x8 load_frag2(const char* lds, int rbase, int c, 
     }
 }
 
+// KS fragment reads with ONE per-lane address register: for a fragment whose first row/col is rbase (a multiple of 16) the byte
+// offset inside the K-tile image is  krow * 2BR + ((2 rbase + 8p) ^ swz(krow)),  krow = 32c + 8g + q (+4),  q = (lane & 15) >> 2,
+// p = lane & 3.  swz depends on the lane only (krow & 3 = q, (krow >> 3) & 1 = g & 1) and occupies bits 5-7, 8p bits 3-4, 2 rbase
+// bits 5-8 and krow * 2BR bits >= 8 (BR = 128) or 9 (BR = 256), so
+//     offset = ks_lane_base(lane) ^ (2 rbase)  +  c * 64 BR  (+ 8 BR for the second half),
+// i.e. one v_xor per fragment and immediates for the rest.  Computing every fragment's address separately costs 12 loop-invariant
+// VGPRs in the 256x256 kernel, which is what made its KS x KS instantiation spill inside the K loop.
+template <int BR> __device__ __forceinline__ int ks_lane_base(int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    return (8 * g + q) * (BR * 2) + ((8 * p) | ((q | ((g & 1) << 2)) << 5));
+}
+template <int BR> __device__ __forceinline__ bf16x8 load_frag_ks(const char* lds, int lane_base, int rbase, int c) {
+    const char* a0 = lds + (lane_base ^ (2 * rbase)) + c * (64 * BR);
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a0));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a0 + 8 * BR));
+    short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
 struct Epi2 {
     const bf16* bias;
     const bf16* residual;
@@ -513,6 +532,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
     PP_BARRIER();
 
     bf16x8 fa[FM], fb[FN];   // one 32-deep fragment set (48 VGPRs)
+    const int ksA0 = ks_lane_base<BM>(lane), ksB0 = ks_lane_base<BN>(lane);
 
     for (int round = 0;; ++round) {
         int nm0 = 0, nn0 = 0;
@@ -536,8 +556,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 
 #define PP_READ(bufA_, bufB_, c_)                                                              \
     do {                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = load_frag2<LB, BN>(bufB_, wn + 16 * j, c_, lane); \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i) fa[i] = load_frag2<LA, BM>(bufA_, wm + 16 * i, c_, lane); \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                       \
+            if constexpr (LB == UCFVIT_LAYOUT_KS) fb[j] = load_frag_ks<BN>(bufB_, ksB, wn + 16 * j, c_);      \
+            else fb[j] = load_frag2<LB, BN>(bufB_, wn + 16 * j, c_, lane);                     \
+        }                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                       \
+            if constexpr (LA == UCFVIT_LAYOUT_KS) fa[i] = load_frag_ks<BM>(bufA_, ksA, wm + 16 * i, c_);      \
+            else fa[i] = load_frag2<LA, BM>(bufA_, wm + 16 * i, c_, lane);                     \
+        }                                                                                      \
     } while (0)
 #define PP_COMPUTE()                                                                           \
     do {                                                                                       \
@@ -579,6 +605,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
         for (int kt = 0; kt < nk; ++kt, ++it) {
             const char* bufA = smem + (it & 1) * BUF;
             const char* bufB = bufA + A_BYTES;
+            int ksA = ksA0, ksB = ksB0;
+            if constexpr (LA == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksA));   // opaque per iteration: the per-fragment XORs are
+            if constexpr (LB == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksB));   // recomputed, not hoisted into 12 live VGPRs
             if (warm_base && kt >= warm_k0) {
                 // pull 1/16 of the tile's C-shaped epilogue input (gelu' pre-activation / residual) into L2 / the memory-side cache
                 // while the MFMAs run, so the epilogue's loads do not pay HBM latency with only a few KB in flight: one 1-KiB DMA
