@@ -56,10 +56,11 @@ class WgradQueue:
             self.items = []
 
 
-# Measured (round 1): the grouped 256x256 ping-pong launch runs the KS x KS weight-gradient problem at ~0.45 PFLOP/s because both
-# operands need hardware-transposed LDS reads (2x the DS instructions + per-fragment address arithmetic), slower than the
-# 128x128 split-K kernel (0.45-0.8 PFLOP/s); so grouping is opt-in until that read path is cheaper.
-_GROUP_WGRAD = __import__("os").environ.get("UCFVIT_WGRAD_GROUPED", "0") == "1"
+# Measured (round 1, ViT-L B=166): the four weight gradients of a Block as ONE grouped 256x256 ping-pong launch take 786 us
+# (1.05 PFLOP/s on 192 of the 256 CUs) against 1142 us as four 128x128 split-K launches, +9.6 % images/s on the whole step.
+# (Before the KS fragment reads moved to inline asm the grouped launch ran at 0.45-0.54 PFLOP/s: hipcc drained the LDS-DMA
+# prefetch in front of every ds_read_tr builtin.)  UCFVIT_WGRAD_GROUPED=0 restores the per-GEMM launches.
+_GROUP_WGRAD = os.environ.get("UCFVIT_WGRAD_GROUPED", "1") != "0"
 
 
 def _wgrad(weight, dy2, x2, queue=None):

@@ -13,7 +13,8 @@ ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3
 ABI_VERSION = 3
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libucfvit_hip.so")
+# UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
+LIB_PATH = os.environ.get("UCFVIT_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libucfvit_hip.so")
 
 
 class GemmDesc(Structure):

@@ -101,6 +101,24 @@ template <int BR> __device__ __forceinline__ bf16x8 load_frag_ks(const char* lds
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// The same read issued from inline asm.  hipcc treats the ds_read_tr builtin as a possible reader of every LDS-DMA in flight and
+// puts `s_waitcnt vmcnt(0)` in front of it: with a KS operand each K-step then waits for the prefetch it has just issued (the
+// K loops of every KS instantiation had that wait; the KC ones, whose fragment reads are plain loads, did not).  asm reads are
+// invisible to that bookkeeping; their own completion is waited for by ks_wait() (lgkmcnt) before the first MFMA that uses them.
+struct KsFrag {
+    u32x2 lo, hi;
+};
+template <int BR, int C> __device__ __forceinline__ void load_frag_ks_asm(KsFrag& f, unsigned img, int lane_base, int rbase) {
+    const unsigned a = img + (unsigned)(lane_base ^ (2 * rbase));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a), "i"(C * 64 * BR));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a), "i"(C * 64 * BR + 8 * BR));
+}
+__device__ __forceinline__ bf16x8 ks_frag_value(const KsFrag& f) {
+    const u32x4 r = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)LDS_PTR(const char, p); }
+
 struct Epi2 {
     const bf16* bias;
     const bf16* residual;
@@ -532,6 +550,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
     PP_BARRIER();
 
     bf16x8 fa[FM], fb[FN];   // one 32-deep fragment set (48 VGPRs)
+    KsFrag ka[FM], kb[FN];   // the same registers while asm reads of a KS operand are in flight
+#define KS_TIE1(f_) "+v"(f_.lo), "+v"(f_.hi)
+#define KS_TIE4(a_) KS_TIE1(a_[0]), KS_TIE1(a_[1]), KS_TIE1(a_[2]), KS_TIE1(a_[3])
+#define KS_TIE8(a_) KS_TIE4(a_), KS_TIE1(a_[4]), KS_TIE1(a_[5]), KS_TIE1(a_[6]), KS_TIE1(a_[7])
     const int ksA0 = ks_lane_base<BM>(lane), ksB0 = ks_lane_base<BN>(lane);
 
     for (int round = 0;; ++round) {
@@ -557,12 +579,23 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #define PP_READ(bufA_, bufB_, c_)                                                              \
     do {                                                                                       \
         _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                       \
-            if constexpr (LB == UCFVIT_LAYOUT_KS) fb[j] = load_frag_ks<BN>(bufB_, ksB, wn + 16 * j, c_);      \
+            if constexpr (LB == UCFVIT_LAYOUT_KS) load_frag_ks_asm<BN, c_>(kb[j], lds_addr(bufB_), ksB, wn + 16 * j); \
             else fb[j] = load_frag2<LB, BN>(bufB_, wn + 16 * j, c_, lane);                     \
         }                                                                                      \
         _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                       \
-            if constexpr (LA == UCFVIT_LAYOUT_KS) fa[i] = load_frag_ks<BM>(bufA_, ksA, wm + 16 * i, c_);      \
+            if constexpr (LA == UCFVIT_LAYOUT_KS) load_frag_ks_asm<BM, c_>(ka[i], lds_addr(bufA_), ksA, wm + 16 * i); \
             else fa[i] = load_frag2<LA, BM>(bufA_, wm + 16 * i, c_, lane);                     \
+        }                                                                                      \
+        if constexpr (LA == UCFVIT_LAYOUT_KS || LB == UCFVIT_LAYOUT_KS) {                      \
+            /* the asm reads have landed before this group leaves its MEM interval; then they become ordinary values */ \
+            if constexpr (LA == UCFVIT_LAYOUT_KS && LB == UCFVIT_LAYOUT_KS)                    \
+                asm volatile("s_waitcnt lgkmcnt(0)" : KS_TIE8(ka), KS_TIE4(kb));               \
+            else if constexpr (LA == UCFVIT_LAYOUT_KS)                                         \
+                asm volatile("s_waitcnt lgkmcnt(0)" : KS_TIE8(ka));                            \
+            else                                                                               \
+                asm volatile("s_waitcnt lgkmcnt(0)" : KS_TIE4(kb));                            \
+            if constexpr (LA == UCFVIT_LAYOUT_KS) { _Pragma("unroll") for (int i = 0; i < FM; ++i) fa[i] = ks_frag_value(ka[i]); } \
+            if constexpr (LB == UCFVIT_LAYOUT_KS) { _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = ks_frag_value(kb[j]); } \
         }                                                                                      \
     } while (0)
 #define PP_COMPUTE()                                                                           \
