@@ -8,8 +8,9 @@ One "step" = forward + cross-entropy + backward (+ data-parallel gradient all-re
 scheduler step on one synthetic batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
 
 metric : images/sec (whole job) for ViT-L/16 224^2, bf16 compute with fp32 master weights (BASELINE.json).
-roofline: the dominant kernel is the bf16 MFMA GEMM (gemm_mfma_kernel<bf16,...>); `achieved` = algorithmic FLOPs of all its
-          launches in the timed region / their HIP-event-measured durations (events recorded on the launch stream).
+roofline: the dominant kernel is the bf16 MFMA GEMM (gemm3_kernel<...>, csrc/gemm2.hip); `achieved` = algorithmic FLOPs of all
+          GEMM launches in the timed region (forward, data gradient, grouped weight gradient) / their HIP-event-measured
+          durations (events recorded on the launch stream).
 cpu_baseline: the CPU oracle's training loop (oracle/ucf_vit_ref.py, kind "port") on this box's host cores, rank 0, N=1 only.
 """
 import argparse
@@ -47,7 +48,7 @@ def train_flops_per_image(w):
 
 
 class GemmProfiler:
-    """HIP-event timing of every ucfvit_gemm launch in the timed region (events on the launch stream)."""
+    """HIP-event timing of every ucfvit_gemm / ucfvit_gemm_grouped launch in the timed region (events on the launch stream)."""
 
     def __init__(self):
         self.records = []   # (start_evt, end_evt, flops, is_mfma_path)
@@ -68,6 +69,18 @@ class GemmProfiler:
             prof.records.append((s, e, 2.0 * M * N * K))
             return out
         ops.gemm = timed_gemm
+        orig_grouped = ops.wgrad_grouped
+
+        def timed_grouped(items):
+            if not prof.enabled:
+                return orig_grouped(items)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig_grouped(items)
+            e.record()
+            prof.records.append((s, e, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)))
+            return out
+        ops.wgrad_grouped = timed_grouped
 
     def summary(self):
         tot_ms, tot_flops = 0.0, 0.0
@@ -232,7 +245,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} train step (fwd+bwd+AdamW), synthetic U{{0..255}} images resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_mfma_kernel<%s> (all fwd/dgrad/wgrad launches of the timed region)" % args.dtype,
+            "roofline": {"bound": "mfma", "kernel": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
+                                             "weight-gradient launch of the timed region)" % args.dtype,
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(args.workload, args.dtype, B), "launches": n_g, "avg_launch_ms": round(g_ms / max(n_g, 1), 4),
                          "avg_launch_gflop": round(g_flops / max(n_g, 1) / 1e9, 2),
