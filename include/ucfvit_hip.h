@@ -96,9 +96,10 @@ typedef struct ucfvit_gemm_desc {
 int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* desc);
 int ucfvit_gemm(const ucfvit_gemm_desc* desc, void* stream);
 
-/* n <= 4 epilogue-free GEMMs with the same K, layouts and dtypes (the four weight gradients of a transformer Block:
- * dW_qkv, dW_proj, dW_fc1, dW_fc2 all contract over the B*N tokens) as ONE persistent launch over the union of their output
- * tiles: fills the 256 CUs without split-K partial sums.  Falls back to n ucfvit_gemm calls when the set is not groupable. */
+/* n <= 32 epilogue-free GEMMs with the same K, layouts and dtypes (the weight gradients dW_qkv, dW_proj, dW_fc1, dW_fc2 of one
+ * or several transformer Blocks all contract over the B*N tokens) as ONE persistent launch over the union of their output tiles:
+ * fills the 256 CUs without split-K partial sums (ViT-L: 192 tiles per Block, so four Blocks = 768 tiles = 3 whole rounds).
+ * Falls back to n ucfvit_gemm calls when the set is not groupable. */
 int ucfvit_gemm_grouped(const ucfvit_gemm_desc* descs, int64_t n, void* stream);
 
 /* column sums  out[n] (fp32) (+)= sum_m x[m][n]   — bias gradients of every nn.Linear (autograd of :159,190,123,127) */

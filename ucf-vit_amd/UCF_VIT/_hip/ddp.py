@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import functional as _HF
 from .params import ensure_store
 
 
@@ -87,7 +88,10 @@ class HipDataParallel(nn.Module):
                 cur_hi = None
         self._pending = [0] * len(self.buckets)
         self._works = []
+        self._ready = []
         self._callback_queued = False
+        if self._hip:
+            _HF.add_wgrad_flush_listener(self._after_wgrad_flush)
         for p in params:
             if p.requires_grad:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -103,7 +107,18 @@ class HipDataParallel(nn.Module):
         b = self.param_bucket[p]
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
-            self._launch(b)
+            if self._hip and _HF.wgrads_pending():
+                # weight gradients are queued for grouped launches that span several Blocks (functional.WgradQueue): this slice is
+                # complete for autograd but not yet on the stream; reduce it when the queue has flushed
+                self._ready.append(b)
+            else:
+                self._launch(b)
+
+    def _after_wgrad_flush(self):
+        ready, self._ready = self._ready, []
+        for b in ready:
+            if self._pending[b] >= 0:
+                self._launch(b)
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
@@ -124,6 +139,8 @@ class HipDataParallel(nn.Module):
         self._pending[b] = -(1 << 30)
 
     def _finish(self):
+        if self._hip:
+            _HF.flush_wgrads()       # (also launches the buckets that were waiting for it)
         # parameters that received no gradient this step (unused) leave their bucket incomplete: reduce it anyway so
         # every rank issues the same collectives in the same order
         for b in range(len(self.buckets)):

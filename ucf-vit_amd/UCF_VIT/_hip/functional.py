@@ -8,6 +8,7 @@ Parameter gradients are written by the kernels straight into the flat fp32 gradi
 HipParamStore when there is one (see params.py); the view is handed to autograd so hooks (e.g. a DDP reducer) still fire.
 """
 import os
+import weakref
 
 import torch
 
@@ -33,11 +34,25 @@ def _ret_grad(g, like):
 
 # ---------------------------------------------------------------------------------------------- param-grad helpers
 class WgradQueue:
-    """Weight gradients of one Block are off the critical path of backward: they are collected and issued as ONE grouped
-    launch (ucfvit_gemm_grouped) when the Block's backward ends, filling the CUs without split-K partial sums."""
+    """Weight gradients are off the critical path of backward: nothing reads them before the optimizer step (or a data-parallel
+    all-reduce).  They are collected and issued as grouped launches (ucfvit_gemm_grouped: one persistent 256x256 ping-pong kernel
+    over the union of the output tiles, no split-K partial sums).  One ViT-L Block has 192 tiles = 75 % of one round of 256 CUs,
+    four Blocks have 768 = three whole rounds, so the queue keeps collecting ACROSS Blocks until the tile count fills whole
+    rounds (>= 95 %) or 32 problems are pending, and the rest goes out when backward ends (autograd engine callback).
+
+    Deferral across Blocks is only used for gradients that land in the flat gradient buffer (params.grad_target gives a view):
+    autograd receives that view before the kernel has run, which is safe because AccumulateGrad adopts it without reading it and
+    every reader of the buffer (optimizer, HipDataParallel bucket launch, grad clipping) comes after flush_wgrads()."""
+
+    MAX_PROBLEMS = 32       # GROUP_MAX of csrc/gemm2.hip
+    CUS = 256
 
     def __init__(self):
-        self.items, self.rets = [], []
+        self.items, self.owners = [], []
+        self.tiles = 0
+        self.deferrable = True
+        self.callback_armed = False
+        self.listeners = []          # called after every flush (HipDataParallel launches the buckets that were waiting for it)
 
     def add(self, weight, dy2, x2):
         out, acc = grad_target(weight)
@@ -45,22 +60,69 @@ class WgradQueue:
         if o2 is None:
             o2 = torch.empty((dy2.shape[1], x2.shape[1]), dtype=torch.float32, device=dy2.device)
             ret = o2.view(weight.shape)
+            self.deferrable = False          # autograd will READ this tensor (clone / accumulate): it must be complete on return
         else:
             ret = None if acc else out
         self.items.append((dy2, x2, o2, acc))
+        # (o2 is a separate view object: holding `out` itself would raise its use count and make AccumulateGrad clone it)
+        self.owners.append((weight, o2) if (out is not None and not acc) else None)
+        self.tiles += ((dy2.shape[1] + 255) // 256) * ((x2.shape[1] + 255) // 256)
         return ret
 
+    def end_block(self):
+        """called when a Block's backward has queued its gradients"""
+        if not self.items:
+            return
+        rounds = -(-self.tiles // self.CUS)
+        full = self.tiles >= 0.95 * rounds * self.CUS
+        if not (_DEFER_WGRAD and self.deferrable) or full or len(self.items) + 4 > self.MAX_PROBLEMS:
+            self.flush()
+        elif not self.callback_armed:
+            self.callback_armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        self.callback_armed = False
+        self.flush()
+
     def flush(self):
-        if self.items:
-            ops.wgrad_grouped(self.items)
-            self.items = []
+        items, owners = self.items, self.owners
+        self.items, self.owners, self.tiles, self.deferrable = [], [], 0, True
+        for i in range(0, len(items), self.MAX_PROBLEMS):
+            ops.wgrad_grouped(items[i:i + self.MAX_PROBLEMS])
+        for ow in owners:
+            # a gradient handed to autograd before it was computed: if AccumulateGrad took a copy instead of the view, refresh it
+            if ow is not None and ow[0].grad is not None and ow[0].grad.data_ptr() != ow[1].data_ptr():
+                ow[0].grad.copy_(ow[1].view(ow[0].shape))
+        for ref in list(self.listeners):
+            fn = ref()
+            if fn is None:
+                self.listeners.remove(ref)       # its HipDataParallel wrapper is gone
+            else:
+                fn()
 
 
 # Measured (round 1, ViT-L B=166): the four weight gradients of a Block as ONE grouped 256x256 ping-pong launch take 786 us
 # (1.05 PFLOP/s on 192 of the 256 CUs) against 1142 us as four 128x128 split-K launches, +9.6 % images/s on the whole step.
 # (Before the KS fragment reads moved to inline asm the grouped launch ran at 0.45-0.54 PFLOP/s: hipcc drained the LDS-DMA
-# prefetch in front of every ds_read_tr builtin.)  UCFVIT_WGRAD_GROUPED=0 restores the per-GEMM launches.
+# prefetch in front of every ds_read_tr builtin.)  UCFVIT_WGRAD_GROUPED=0 restores the per-GEMM launches,
+# UCFVIT_WGRAD_DEFER=0 keeps one launch per Block.
 _GROUP_WGRAD = os.environ.get("UCFVIT_WGRAD_GROUPED", "1") != "0"
+_DEFER_WGRAD = os.environ.get("UCFVIT_WGRAD_DEFER", "1") != "0"
+_WQ = WgradQueue()
+
+
+def flush_wgrads():
+    """issue every pending weight-gradient launch"""
+    _WQ.flush()
+
+
+def wgrads_pending():
+    return bool(_WQ.items)
+
+
+def add_wgrad_flush_listener(bound_method):
+    _WQ.listeners.append(weakref.WeakMethod(bound_method))
 
 
 def _wgrad(weight, dy2, x2, queue=None):
@@ -316,12 +378,12 @@ class BlockFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         c = lambda p: compute_param(p, cdtype)
         dy2 = _as(dy, cdtype).reshape(x2.shape)
-        wq = WgradQueue()
+        wq = _WQ
         dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq)
         dx1, g_n2w, g_n2b = _ln_bwd(dln2, x1, c(n2w), mean2, rstd2, n2w, n2b, dres=dy2)        # + residual branch
         dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7], tp, wq)
         dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1)
-        wq.flush()                                                                              # the Block's 4 weight gradients, one launch
+        wq.end_block()                                   # the Block's 4 weight gradients: grouped launch now, or with the next Blocks'
         return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None)
 
 

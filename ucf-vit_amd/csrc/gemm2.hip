@@ -469,7 +469,8 @@ template <int LAYOUT> __device__ __forceinline__ int64_t k_byte_off(int k0, int6
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
 
-// up to 4 GEMMs of one launch (same K, layouts and output type): the weight gradients of a transformer block
+// up to GROUP_MAX GEMMs of one launch (same K, layouts and output type): the weight gradients of one or several transformer blocks
+constexpr int GROUP_MAX = 32;   // 32 x 72-byte problem records stay inside the 4-KiB kernel-argument segment
 struct Problem3 {
     const void* A;
     const void* B;
@@ -478,7 +479,7 @@ struct Problem3 {
     int M, N, tiles_m, tiles_n, tile_start, accumulate;
 };
 struct Groups3 {
-    Problem3 p[4];
+    Problem3 p[GROUP_MAX];
     int n, total_tiles;
 };
 
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #define PP_SELECT(t_, Ab_, Bb_, C_, M_, N_, lda_, ldb_, ldc_, acc_, m0_, n0_)                 \
     do {                                                                                       \
         int gi = 0;                                                                            \
-        _Pragma("unroll") for (int q = 1; q < 4; ++q) if (q < gt.n && (t_) >= gt.p[q].tile_start) gi = q; \
+        for (int q = 1; q < gt.n; ++q) if ((t_) >= gt.p[q].tile_start) gi = q;                 \
         const Problem3& P = gt.p[gi];                                                          \
         Ab_ = reinterpret_cast<const char*>(P.A);                                              \
         Bb_ = reinterpret_cast<const char*>(P.B);                                              \
@@ -1203,10 +1204,10 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
 }
 
 
-// Grouped launch: n <= 4 epilogue-free GEMMs with identical K, layouts and dtypes (the four weight gradients of a Block) run
+// Grouped launch: n <= 32 epilogue-free GEMMs with identical K, layouts and dtypes (the weight gradients of 1..8 Blocks) run
 // as ONE persistent ping-pong launch over the union of their 256x256 tiles — no split-K, no partial-sum slabs.
 extern "C" int ucfvit_gemm_grouped(const ucfvit_gemm_desc* descs, int64_t n, void* stream) {
-    UCF_CHECK_ARG(descs && n >= 1 && n <= 4, "ucfvit_gemm_grouped: need 1..4 descriptors");
+    UCF_CHECK_ARG(descs && n >= 1 && n <= GROUP_MAX, "ucfvit_gemm_grouped: need 1..%d descriptors", GROUP_MAX);
     const ucfvit_gemm_desc& d0 = descs[0];
     bool fast = d0.dtype == UCFVIT_BF16 && pp_enabled() && d0.K >= 128;
     for (int64_t i = 0; i < n && fast; ++i) {
