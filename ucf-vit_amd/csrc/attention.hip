@@ -18,8 +18,8 @@
 // attention_short.hip: whole-sequence-in-LDS kernels for N <= 256 (return 1 = handled, 0 = not applicable, <0 = error)
 int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
                                hipStream_t s);
-int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
-                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s);
+int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
+                               float scale, int dtype, hipStream_t s);
 int ucfvit_attention_short_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
                                int64_t H, int64_t dh, float scale, int dtype, hipStream_t s);
 
@@ -502,19 +502,18 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N
 template <typename T, int DH>
 int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int64_t B, int64_t N,
                     int64_t H, float scale, hipStream_t s) {
+    // the FUSED backward (one launch, operands read once, delta taken from P and dP inside) is the default where it applies
+    static const bool fused_bwd = [] { const char* e = getenv("UCFVIT_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+    if (short_enabled() && fused_bwd) {
+        const int rc = ucfvit_attention_fused_bwd(qkv, dout, lse, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
+        if (rc == 1) return UCFVIT_OK;
+        if (rc < 0) return rc;
+    }
     const int64_t nd = B * N * H * (DH / (16 / (int64_t)sizeof(T)));
     hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, B,
                        (int)N, (int)H);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");
-    // measured (ViT-L, N=197, B=166): the resident backward kernels (541 us) are slower than the streaming pair (430 us), the
-    // resident forward (106 us) is faster than the streaming one (115 us): backward stays streaming unless asked otherwise
-    // the FUSED resident backward (Q, K, V, dO all in LDS, one read of the operands, one launch) is the default where it applies
-    static const bool fused_bwd = [] { const char* e = getenv("UCFVIT_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
-    if (short_enabled() && fused_bwd) {
-        const int rc = ucfvit_attention_fused_bwd(qkv, dout, lse, delta, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
-        if (rc == 1) return UCFVIT_OK;
-        if (rc < 0) return rc;
-    }
+    // measured (ViT-L, N=197, B=166): the two-kernel resident backward (541 us) is slower than the streaming pair (430 us)
     static const bool short_bwd = [] { const char* e = getenv("UCFVIT_ATTN_SHORT_BWD"); return e && e[0] == '1'; }();
     if (short_enabled() && short_bwd) {
         const int rc = ucfvit_attention_short_bwd(qkv, dout, lse, delta, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);

@@ -417,35 +417,14 @@ int launch_bwd(const void* qkv, const void* dout, const float* lse, const float*
 
 
 // =====================================================================================================================
-// backward, fused (bf16, head dim 64): Q, K, V and dO of one (batch, head) are ALL resident in LDS (4 x 28 KiB for N = 197), read
-// from HBM once.  Phase A: each wave takes query blocks and produces dQ (K, V resident); phase B: each wave takes key blocks and
-// produces dK, dV (Q, dO resident) — the two formulations of the two-kernel backward, without the second read of the operands,
-// without the 64-row tile padding (13 x 13 blocks of 16 instead of 16 x 16) and without the re-reads of Q / dO per key tile.
-// 8 waves; phase B walks the key blocks in reverse wave order so that 13 + 13 blocks spread as 3-4 per wave.
+// backward, fused (bf16, head dim 64, N <= 208): ONE launch per attention layer instead of delta + dQ + dK/dV.
+// Phase A: each wave takes query blocks and produces dQ with K and V resident in LDS; phase B: each wave takes key blocks and
+// produces dK, dV with Q and dO resident — the two formulations of the two-kernel backward, without the 64-row tile padding
+// (13 x 13 blocks of 16 instead of 16 x 16 for N = 197) and without the re-reads of Q / dO per key tile.
 // Every LDS address is one of six per-lane bases plus an immediate (row images: base ^ 64 c + 2048 block; transposed reads:
-// base ^ 32 d + 4096 chunk), which keeps the kernel inside 256 VGPRs — the earlier resident dQ / dKdV kernels computed each
-// fragment address separately and spilled (slower than the streaming kernels).
+// base ^ 32 d + 4096 chunk) and sched_barriers keep hipcc from hoisting all fragment reads of a phase: 218 VGPRs, no spills
+// (the earlier resident dQ / dKdV kernels spilled 124-564 bytes per lane and were slower than the streaming kernels).
 // =====================================================================================================================
-constexpr int AF_THREADS = 512, AF_WAVES = 8;
-
-template <int ROWS>
-__device__ __forceinline__ void af_load_image(char* lds, const bf16* __restrict__ base, int64_t row_stride, int R, int tid) {
-    constexpr int SPR = 8, NIT = (ROWS * SPR + AF_THREADS - 1) / AF_THREADS;
-    u32x4 v[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int p = tid + i * AF_THREADS;
-        const int row = p / SPR, slot = p % SPR;
-        v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (p < ROWS * SPR && row < R) v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + slot * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int p = tid + i * AF_THREADS;
-        if (p < ROWS * SPR) *reinterpret_cast<u32x4*>(lds + img_off<bf16, 64>(p / SPR, p % SPR)) = v[i];
-    }
-}
-
 __device__ __forceinline__ bf16x8 af_row(const char* img, int base_c, int blk) {      // rows 16 blk .. 16 blk + 15, k-chunk c
     return *reinterpret_cast<const bf16x8*>(img + base_c + blk * 2048);
 }
@@ -457,18 +436,46 @@ __device__ __forceinline__ bf16x8 af_tr(const char* img, int base_d, int rc) {  
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// Only TWO images are resident at a time (K, V for phase A, then Q, dO for phase B), so two workgroups of 4 waves fit a CU
+// (58 KiB of LDS each) and one workgroup's loads overlap the other's MFMA/softmax work (all four images in one 8-wave workgroup
+// measured 273 us per layer at ViT-L B=166, this form 222 us, the streaming pair + delta kernel 413 us); the Q / dO images of
+// phase B are fetched into registers BEFORE phase A starts and stored to LDS after it.  The blocks a wave owns in a phase come
+// straight from global memory as MFMA fragments (the lines were just read for the images: L2 hits).  delta = rowsum(dO o O) is
+// taken in phase A as sum_k P dP from values the wave holds anyway, so no delta kernel and no read of O.
+constexpr int AG_THREADS = 256, AG_WAVES = 4;
+
+template <int ROWS> struct AgStage {
+    static constexpr int NIT = (ROWS * 8 + AG_THREADS - 1) / AG_THREADS;
+    u32x4 v[NIT];
+};
+template <int ROWS>
+__device__ __forceinline__ void ag_fetch(AgStage<ROWS>& st, const bf16* __restrict__ base, int64_t row_stride, int R, int tid) {
+#pragma unroll
+    for (int i = 0; i < AgStage<ROWS>::NIT; ++i) {
+        const int p = tid + i * AG_THREADS;
+        const int row = p >> 3, slot = p & 7;
+        st.v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (p < ROWS * 8 && row < R) st.v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + slot * 8);
+    }
+}
+template <int ROWS> __device__ __forceinline__ void ag_store(const AgStage<ROWS>& st, char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < AgStage<ROWS>::NIT; ++i) {
+        const int p = tid + i * AG_THREADS;
+        if (p < ROWS * 8) *reinterpret_cast<u32x4*>(lds + img_off<bf16, 64>(p >> 3, p & 7)) = st.v[i];
+    }
+}
+
 template <int NB, bool EXACT>
-__global__ __launch_bounds__(AF_THREADS) void attn_f_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
+__global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                                 const float* __restrict__ lse, bf16* __restrict__ dqkv, int N, int H,
+                                                                 float scale, float scale_log2e) {
     typedef bf16 T;
-    constexpr int DH = 64, NCH = 2, NDB = 4, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * 128;
+    constexpr int DH = 64, NDB = 4, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsQ = smem;
-    char* ldsK = smem + IMG;
-    char* ldsV = smem + 2 * IMG;
-    char* ldsDO = smem + 3 * IMG;
-    float* ldsLse = reinterpret_cast<float*>(smem + 4 * IMG);   // [ROWS]
+    char* slot0 = smem;                 // K, then Q
+    char* slot1 = smem + IMG;           // V, then dO
+    float* ldsLse = reinterpret_cast<float*>(smem + 2 * IMG);   // [ROWS]
     float* ldsDelta = ldsLse + ROWS;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -478,45 +485,62 @@ __global__ __launch_bounds__(AF_THREADS) void attn_f_bwd_kernel(const bf16* __re
     const int64_t rs = 3 * (int64_t)D;
     const T* qbase = qkv + b * N * rs + h * DH;
     const T* dobase = dout + b * N * (int64_t)D + h * DH;
-    af_load_image<ROWS>(ldsQ, qbase, rs, N, tid);
-    af_load_image<ROWS>(ldsK, qbase + D, rs, N, tid);
-    af_load_image<ROWS>(ldsV, qbase + 2 * D, rs, N, tid);
-    af_load_image<ROWS>(ldsDO, dobase, D, N, tid);
-    for (int i = tid; i < ROWS; i += AF_THREADS) {
-        ldsLse[i] = i < N ? lse[(b * H + h) * N + i] : INFINITY;    // +inf -> P = 0 for padding queries
-        ldsDelta[i] = i < N ? delta[(b * H + h) * N + i] : 0.f;
+    const float* lse_bh = lse + (b * H + h) * N;
+    {
+        AgStage<ROWS> sk, sv;
+        ag_fetch<ROWS>(sk, qbase + D, rs, N, tid);
+        ag_fetch<ROWS>(sv, qbase + 2 * D, rs, N, tid);
+        ag_store<ROWS>(sk, slot0, tid);
+        ag_store<ROWS>(sv, slot1, tid);
     }
+    for (int i = tid; i < ROWS; i += AG_THREADS) {
+        ldsLse[i] = i < N ? lse_bh[i] : INFINITY;    // +inf -> P = 0 for padding queries
+        ldsDelta[i] = 0.f;                           // phase A fills the blocks that exist
+    }
+    AgStage<ROWS> sq, sdo;                           // phase B's images travel while phase A computes
+    ag_fetch<ROWS>(sq, qbase, rs, N, tid);
+    ag_fetch<ROWS>(sdo, dobase, D, N, tid);
     __syncthreads();
 
-    // per-lane address bases (see header)
     const int rowb0 = li * 128 + ((g ^ (li & 7)) << 4), rowb1 = rowb0 ^ 64;
     const int tq = li >> 2, tp = li & 3;
     const int trb = (4 * g + tq) * 128 + ((((tp >> 1) ^ (4 * (g & 1) + tq))) << 4) + (tp & 1) * 8;
     constexpr int nb_ = NB;
-
-    // ---------------- phase A: dQ, query blocks per wave -------------------------------------------------------------
     const int nqb = (N + 15) / 16;
-    for (int qb = wave; qb < nqb; qb += AF_WAVES) {
+
+    // ---------------- phase A: dQ (K in slot 0, V in slot 1) -----------------------------------------------------------
+    for (int qb = wave; qb < nqb; qb += AG_WAVES) {
         const int q = qb * 16 + li;
-        const bf16x8 qf0 = af_row(ldsQ, rowb0, qb), qf1 = af_row(ldsQ, rowb1, qb);
-        const bf16x8 do0 = af_row(ldsDO, rowb0, qb), do1 = af_row(ldsDO, rowb1, qb);
-        const float my_lse = ldsLse[q], my_delta = ldsDelta[q];
-        f32x4 ds[NB];
+        const bf16x8 qf0 = s_frag_global<T, DH>(qbase, rs, q, N, 0, lane), qf1 = s_frag_global<T, DH>(qbase, rs, q, N, 1, lane);
+        const bf16x8 do0 = s_frag_global<T, DH>(dobase, D, q, N, 0, lane), do1 = s_frag_global<T, DH>(dobase, D, q, N, 1, lane);
+        const float my_lse = ldsLse[q];
+        // delta[q] = sum_d dO[q][d] O[q][d] = sum_k P[q][k] dP[q][k]: taken here from the P and dP this wave holds anyway (one row of
+        // queries per lane column), so the separate delta kernel and its read of O and dO are not needed
+        f32x4 ds[NB], dpk[NB];
+        float dl = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            MmaS<T>::mma(sacc, af_row(ldsK, rowb0, kb), qf0);
-            MmaS<T>::mma(sacc, af_row(ldsK, rowb1, kb), qf1);
-            MmaS<T>::mma(dp, af_row(ldsV, rowb0, kb), do0);
-            MmaS<T>::mma(dp, af_row(ldsV, rowb1, kb), do1);
+            MmaS<T>::mma(sacc, af_row(slot0, rowb0, kb), qf0);
+            MmaS<T>::mma(sacc, af_row(slot0, rowb1, kb), qf1);
+            MmaS<T>::mma(dp, af_row(slot1, rowb0, kb), do0);
+            MmaS<T>::mma(dp, af_row(slot1, rowb1, kb), do1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -my_lse));
                 if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) p = (kb * 16 + 4 * g + r < N) ? p : 0.f;     // ragged key block only
-                ds[kb][r] = p * (dp[r] - my_delta);
+                ds[kb][r] = p;
+                dl = fmaf(p, dp[r], dl);
             }
-            if (kb & 1) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every block's fragment reads (spills)
+            dpk[kb] = dp;
+            if (kb & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        const float my_delta = gsum(dl);
+        if (g == 0) ldsDelta[q] = my_delta;           // phase B reads it (after the barrier between the phases)
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[kb][r] *= dpk[kb][r] - my_delta;
         f32x4 dq[NDB];
 #pragma unroll
         for (int d = 0; d < NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_f_bwd_kernel(const bf16* __re
         for (int rc = 0; rc < NRC; ++rc) {
             const bf16x8 f = s_frag_acc<T, nb_>(ds, rc);
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(dq[d], af_tr(ldsK, trb ^ (d << 5), rc), f);
+            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(dq[d], af_tr(slot0, trb ^ (d << 5), rc), f);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < N) {
@@ -538,21 +562,24 @@ __global__ __launch_bounds__(AF_THREADS) void attn_f_bwd_kernel(const bf16* __re
             }
         }
     }
+    __syncthreads();                     // every wave is done with K and V
+    ag_store<ROWS>(sq, slot0, tid);
+    ag_store<ROWS>(sdo, slot1, tid);
+    __syncthreads();
 
-    // ---------------- phase B: dK, dV, key blocks per wave (reverse wave order) ---------------------------------------
-    const int nkb = nqb;
-    for (int kb = AF_WAVES - 1 - wave; kb < nkb; kb += AF_WAVES) {
+    // ---------------- phase B: dK, dV (Q in slot 0, dO in slot 1), reverse wave order -----------------------------------
+    for (int kb = AG_WAVES - 1 - wave; kb < nqb; kb += AG_WAVES) {
         const int key = kb * 16 + li;
-        const bf16x8 kf0 = af_row(ldsK, rowb0, kb), kf1 = af_row(ldsK, rowb1, kb);
-        const bf16x8 vf0 = af_row(ldsV, rowb0, kb), vf1 = af_row(ldsV, rowb1, kb);
+        const bf16x8 kf0 = s_frag_global<T, DH>(qbase + D, rs, key, N, 0, lane), kf1 = s_frag_global<T, DH>(qbase + D, rs, key, N, 1, lane);
+        const bf16x8 vf0 = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, 0, lane), vf1 = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, 1, lane);
         f32x4 pm[NB], ds[NB];
 #pragma unroll
         for (int qb = 0; qb < NB; ++qb) {
             f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            MmaS<T>::mma(sacc, af_row(ldsQ, rowb0, qb), kf0);
-            MmaS<T>::mma(sacc, af_row(ldsQ, rowb1, qb), kf1);
-            MmaS<T>::mma(dp, af_row(ldsDO, rowb0, qb), vf0);
-            MmaS<T>::mma(dp, af_row(ldsDO, rowb1, qb), vf1);
+            MmaS<T>::mma(sacc, af_row(slot0, rowb0, qb), kf0);
+            MmaS<T>::mma(sacc, af_row(slot0, rowb1, qb), kf1);
+            MmaS<T>::mma(dp, af_row(slot1, rowb0, qb), vf0);
+            MmaS<T>::mma(dp, af_row(slot1, rowb1, qb), vf1);
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsLse + qb * 16 + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
 #pragma unroll
@@ -575,8 +602,8 @@ __global__ __launch_bounds__(AF_THREADS) void attn_f_bwd_kernel(const bf16* __re
             const bf16x8 fs = s_frag_acc<T, nb_>(ds, rc);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
-                MmaS<T>::mma(dv[d], af_tr(ldsDO, trb ^ (d << 5), rc), fp);
-                MmaS<T>::mma(dk[d], af_tr(ldsQ, trb ^ (d << 5), rc), fs);
+                MmaS<T>::mma(dv[d], af_tr(slot1, trb ^ (d << 5), rc), fp);
+                MmaS<T>::mma(dk[d], af_tr(slot0, trb ^ (d << 5), rc), fs);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -599,22 +626,21 @@ __global__ __launch_bounds__(AF_THREADS) void attn_f_bwd_kernel(const bf16* __re
 }
 
 template <int NB>
-int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N, int64_t H,
-                     float scale, hipStream_t s) {
+int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
     constexpr int ROWS = ((NB + 1) / 2) * 32;
-    constexpr size_t smem = 4 * (size_t)ROWS * 128 + 2 * ROWS * sizeof(float);
+    constexpr size_t smem = 2 * (size_t)ROWS * 128 + 2 * ROWS * sizeof(float);
     const float sl2 = scale * 1.44269504088896340736f;
-    const dim3 grid((unsigned)(B * H)), block(AF_THREADS);
+    const dim3 grid((unsigned)(B * H)), block(AG_THREADS);
     if ((N + 15) / 16 == NB) {
-        if (int rc = big_lds(attn_f_bwd_kernel<NB, true>, smem)) return rc;
-        hipLaunchKernelGGL((attn_f_bwd_kernel<NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv,
-                           (int)N, (int)H, scale, sl2);
+        if (int rc = big_lds(attn_g_bwd_kernel<NB, true>, smem)) return rc;
+        hipLaunchKernelGGL((attn_g_bwd_kernel<NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+                           (int)H, scale, sl2);
     } else {
-        if (int rc = big_lds(attn_f_bwd_kernel<NB, false>, smem)) return rc;
-        hipLaunchKernelGGL((attn_f_bwd_kernel<NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv,
-                           (int)N, (int)H, scale, sl2);
+        if (int rc = big_lds(attn_g_bwd_kernel<NB, false>, smem)) return rc;
+        hipLaunchKernelGGL((attn_g_bwd_kernel<NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+                           (int)H, scale, sl2);
     }
-    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(fused resident)");
+    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(fused)");
     return UCFVIT_OK;
 }
 
@@ -646,14 +672,14 @@ int ucfvit_attention_short_bwd(const void* qkv, const void* dout, const float* l
     AS_PICK(launch_bwd, bf16, 32, qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
 }
 
-// fused resident backward (bf16, head dim 64, N <= 256): 1 = handled, 0 = not applicable, <0 = error
-int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
-                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s) {
-    if (dtype != UCFVIT_BF16 || N > 208 || dh != 64 || B * H >= (1ll << 31)) return 0;   // 14..16 blocks: spills, the streaming pair runs
+// fused backward (bf16, head dim 64, N <= 208; needs no delta): 1 = handled, 0 = not applicable, <0 = error
+int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
+                               float scale, int dtype, hipStream_t s) {
+    if (dtype != UCFVIT_BF16 || N > 208 || dh != 64 || B * H >= (1ll << 31)) return 0;   // 14..16 blocks would spill: streaming pair
     const int nb = (int)((N + 15) / 16);
     int rc;
-    if (nb <= 4) rc = launch_fused_bwd<4>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
-    else if (nb <= 8) rc = launch_fused_bwd<8>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
-    else rc = launch_fused_bwd<13>(qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
+    if (nb <= 4) rc = launch_fused_bwd<4>(qkv, dout, lse, dqkv, B, N, H, scale, s);
+    else if (nb <= 8) rc = launch_fused_bwd<8>(qkv, dout, lse, dqkv, B, N, H, scale, s);
+    else rc = launch_fused_bwd<13>(qkv, dout, lse, dqkv, B, N, H, scale, s);
     return rc == UCFVIT_OK ? 1 : rc;
 }
