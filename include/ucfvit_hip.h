@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 3
+#define UCFVIT_ABI_VERSION 4
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -90,11 +90,20 @@ typedef struct ucfvit_gemm_desc {
     float alpha;
     void* workspace;         /* optional fp32 scratch for split-K partial sums (see ucfvit_gemm_workspace), or NULL */
     int64_t workspace_bytes;
+    float* c_colsum_partial; /* optional by-product of the epilogue: per block of output rows, the column sums of the values written to
+                              * C (taken in fp32 before the rounding to dtype): fp32 [ucfvit_gemm_colsum_rows(desc)][N], every entry
+                              * written.  Summed over its rows (ucfvit_reduce_rows) it is the bias gradient of the Linear layer whose
+                              * output gradient this GEMM produces (fc1: C = dh), so dh is not read again by ucfvit_colsum.  NULL: off. */
 } ucfvit_gemm_desc;
 
 /* bytes of workspace the split-K path would use for this problem (0: none).  Without it the GEMM still runs, un-split. */
 int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* desc);
 int ucfvit_gemm(const ucfvit_gemm_desc* desc, void* stream);
+/* rows of desc->c_colsum_partial this problem would write (desc->c_colsum_partial itself is not read); 0: the kernel that runs this
+ * problem has no such by-product and ucfvit_gemm rejects a non-NULL c_colsum_partial with UCFVIT_ERR_UNSUPPORTED. */
+int64_t ucfvit_gemm_colsum_rows(const ucfvit_gemm_desc* desc);
+/* out[n] (+)= sum_r partial[r][n]  (fp32, fixed order) — the second stage of every two-stage column sum of this library */
+int ucfvit_reduce_rows(const float* partial, float* out, int64_t rows, int64_t N, int accumulate, void* stream);
 
 /* n <= 32 epilogue-free GEMMs with the same K, layouts and dtypes (the weight gradients dW_qkv, dW_proj, dW_fc1, dW_fc2 of one
  * or several transformer Blocks all contract over the B*N tokens) as ONE persistent launch over the union of their output tiles:

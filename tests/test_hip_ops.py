@@ -348,3 +348,22 @@ def test_wgrad_grouped_one_launch(Mtok, D):
     outs3 = ops.wgrad_grouped([(a, b, None, False) for a, b, _, _ in items])
     for a, b in zip(outs2, outs3):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,Nout,Kc", [(25216, 512, 256), (700, 384, 136)])
+def test_dgrad_output_column_sums_byproduct(M, Nout, Kc):
+    """dx = (dy·W) * aux with the column sums of dx (= bias gradient of the layer before) as a by-product of the same launch
+    (desc.c_colsum_partial + ucfvit_reduce_rows on the 256x256 kernel: first shape, 99 x 2 tiles; separate column-sum pass on the
+    second); overwrite, then accumulate.  The sums are taken in fp32 before dx is rounded to bf16."""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(M + Nout)
+    dy = torch.randn(M, Kc, generator=gen).bfloat16()
+    wT = (torch.randn(Nout, Kc, generator=gen) * 0.1).bfloat16()          # transposed weight: dx[M,Nout] = dy[M,Kc]·wT[Nout,Kc]ᵀ
+    aux = torch.randn(M, Nout, generator=gen).bfloat16()
+    ref = (dy.double() @ wT.double().T) * aux.double()
+    cs = torch.full((Nout,), 5.0, device=DEV)
+    dx = ops.linear_dgrad_t(dy.to(DEV), wT.to(DEV), act_grad_aux=aux.to(DEV), aux_is_deriv=True, c_colsum=cs)
+    assert rel_err(dx.float(), ref) < 1e-2
+    assert rel_err(cs, ref.sum(0)) < 2e-3
+    ops.linear_dgrad_t(dy.to(DEV), wT.to(DEV), act_grad_aux=aux.to(DEV), aux_is_deriv=True, c_colsum=cs, c_colsum_accumulate=True)
+    assert rel_err(cs, 2 * ref.sum(0)) < 2e-3

@@ -152,15 +152,17 @@ def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None):
     return dx, (None if aw else dg), (None if ab else db)
 
 
-def _dgrad(dy2, p_w, w, aux=None, aux_is_deriv=False):
+def _dgrad(dy2, p_w, w, aux=None, aux_is_deriv=False, c_colsum=None, c_colsum_accumulate=False):
     """dx = dy·W (optionally x gelu'(aux), or x aux when aux already is the derivative); uses the transposed weight shadow
-    when the flat store keeps one"""
+    when the flat store keeps one.  c_colsum: fp32 [K] that receives the column sums of dx (bias gradient of the layer before)."""
     wT = compute_param_t(p_w, dy2.dtype)
     if wT is not None:
-        return ops.linear_dgrad_t(dy2, wT, act_grad_aux=aux, aux_is_deriv=aux_is_deriv)
-    return ops.linear_dgrad(dy2, w, act_grad_aux=aux, aux_is_deriv=aux_is_deriv)
+        return ops.linear_dgrad_t(dy2, wT, act_grad_aux=aux, aux_is_deriv=aux_is_deriv, c_colsum=c_colsum,
+                                  c_colsum_accumulate=c_colsum_accumulate)
+    return ops.linear_dgrad(dy2, w, act_grad_aux=aux, aux_is_deriv=aux_is_deriv, c_colsum=c_colsum, c_colsum_accumulate=c_colsum_accumulate)
 
 
+_BIAS_FROM_EPILOGUE = os.environ.get("UCFVIT_BIAS_FROM_EPILOGUE", "1") != "0"   # A/B switch
 _GELU_SAVE_DERIV = os.environ.get("UCFVIT_GELU_SAVE_DERIV", "1") != "0"     # A/B switch
 
 
@@ -248,9 +250,18 @@ def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=
     h, a = saved
     g_w2 = _wgrad(p_w2, dy2, a, wq) if needs[2] else None
     g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
-    dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype))   # dgrad fused with gelu'(pre-activation)
+    # dgrad fused with gelu'(pre-activation); the fc1 bias gradient = column sums of dh comes out of the same epilogue
+    need_b1 = p_b1 is not None and needs[1]
+    if need_b1 and _BIAS_FROM_EPILOGUE:
+        bout, bacc = grad_target(p_b1)
+        if bout is None:
+            bout = torch.empty(p_b1.shape, dtype=torch.float32, device=dy2.device)
+        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype), c_colsum=bout, c_colsum_accumulate=bacc)
+        g_b1 = None if bacc else bout
+    else:
+        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype))
+        g_b1 = _bgrad(p_b1, dh) if need_b1 else None
     g_w1 = _wgrad(p_w1, dh, x2, wq) if needs[0] else None
-    g_b1 = _bgrad(p_b1, dh) if (p_b1 is not None and needs[1]) else None
     dx = _dgrad(dh, p_w1, w1)
     if tp:
         tp.all_reduce(dx)                                              # C4: entry gradient all-reduce

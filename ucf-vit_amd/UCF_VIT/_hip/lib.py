@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
@@ -28,6 +28,7 @@ class GemmDesc(Structure):
         ("act", c_int32), ("accumulate", c_int32),
         ("alpha", c_float),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("c_colsum_partial", c_void_p),
     ]
 
 
@@ -38,6 +39,8 @@ SIGNATURES = {
     "ucfvit_last_error": (c_char_p, []),
     "ucfvit_gemm_workspace": (c_int64, [POINTER(GemmDesc)]),
     "ucfvit_gemm": (c_int, [POINTER(GemmDesc), _P]),
+    "ucfvit_gemm_colsum_rows": (c_int64, [POINTER(GemmDesc)]),
+    "ucfvit_reduce_rows": (c_int, [_P, _P, _I64, _I64, _I, _P]),
     "ucfvit_gemm_grouped": (c_int, [POINTER(GemmDesc), _I64, _P]),
     "ucfvit_colsum_workspace": (c_int64, [_I64, _I64]),
     "ucfvit_colsum": (c_int, [_P, _P, _I64, _I64, _I64, _I, _P, _I, _P]),

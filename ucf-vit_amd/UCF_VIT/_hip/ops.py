@@ -52,8 +52,10 @@ def workspace(nbytes, device):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None, residual=None, act=ACT_NONE,
-         aux_in=None, aux_out=None, accumulate=False, alpha=1.0):
-    """C[M,N] = epilogue(alpha * op(A)·op(B)); A, B are 2-D row-major tensors (see include/ucfvit_hip.h)."""
+         aux_in=None, aux_out=None, accumulate=False, alpha=1.0, c_colsum=None, c_colsum_accumulate=False):
+    """C[M,N] = epilogue(alpha * op(A)·op(B)); A, B are 2-D row-major tensors (see include/ucfvit_hip.h).
+    c_colsum: optional fp32 [N] tensor that receives (+)= the column sums of C — as a by-product of the epilogue where the library
+    has one (desc.c_colsum_partial + ucfvit_reduce_rows), else by a separate ucfvit_colsum pass over C."""
     L = _l.load()
     _chk(A, "gemm.A"), _chk(B, "gemm.B")
     if A.dtype != B.dtype:
@@ -72,12 +74,28 @@ def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None,
     d.dtype, d.out_dtype = dt(A), dt(out)
     d.act, d.accumulate, d.alpha = act, 1 if accumulate else 0, alpha
     d.workspace, d.workspace_bytes = None, 0
+    d.c_colsum_partial = None
+    cs_rows, cs_part = 0, None
+    if c_colsum is not None:
+        _chk(c_colsum, "gemm.c_colsum")
+        if c_colsum.dtype != torch.float32 or c_colsum.numel() != N or not c_colsum.is_contiguous():
+            raise TypeError("gemm: c_colsum must be a contiguous fp32 tensor of N elements")
+        cs_rows = L.ucfvit_gemm_colsum_rows(ctypes.byref(d))
+        if cs_rows > 0:
+            cs_part = workspace(cs_rows * N * 4, A.device)
+            d.c_colsum_partial = cs_part.data_ptr()
     if act == ACT_NONE and bias is None and residual is None:      # only epilogue-free GEMMs (weight gradients) split K
         need = L.ucfvit_gemm_workspace(ctypes.byref(d))
         if need > 0:
             ws = workspace(need, A.device)
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _l.check(L.ucfvit_gemm(ctypes.byref(d), _stream()), "ucfvit_gemm")
+    if c_colsum is not None:
+        if cs_rows > 0:
+            _l.check(L.ucfvit_reduce_rows(cs_part.data_ptr(), c_colsum.data_ptr(), cs_rows, N, 1 if c_colsum_accumulate else 0, _stream()),
+                     "ucfvit_reduce_rows")
+        else:
+            colsum(out, out=c_colsum, accumulate=c_colsum_accumulate)
     return out
 
 
@@ -121,12 +139,13 @@ def _dgrad_act(act_grad_aux, aux_is_deriv):
     return ACT_MUL_AUX if aux_is_deriv else ACT_GELU_GRAD
 
 
-def linear_dgrad(dy2, w, act_grad_aux=None, out=None, aux_is_deriv=False):
+def linear_dgrad(dy2, w, act_grad_aux=None, out=None, aux_is_deriv=False, c_colsum=None, c_colsum_accumulate=False):
     """dx[M,K] = dy2[M,N]·w[N,K], optionally times gelu'(aux) (aux = the fc1 pre-activation) or times aux itself
     (aux_is_deriv: aux = gelu' saved by the forward epilogue, ACT_GELU_SAVE_DERIV)"""
     M, N = dy2.shape
     K = w.shape[1]
-    return gemm(dy2, w, M, K, N, LAYOUT_KC, LAYOUT_KS, out=out, act=_dgrad_act(act_grad_aux, aux_is_deriv), aux_in=act_grad_aux)
+    return gemm(dy2, w, M, K, N, LAYOUT_KC, LAYOUT_KS, out=out, act=_dgrad_act(act_grad_aux, aux_is_deriv), aux_in=act_grad_aux,
+                c_colsum=c_colsum, c_colsum_accumulate=c_colsum_accumulate)
 
 
 def linear_wgrad(dy2, x2, out=None, accumulate=False):
@@ -359,8 +378,9 @@ def transpose_batched(src_flat, dst_flat, table, n_mats, total_tiles):
              "ucfvit_transpose_batched")
 
 
-def linear_dgrad_t(dy2, wT, act_grad_aux=None, out=None, aux_is_deriv=False):
+def linear_dgrad_t(dy2, wT, act_grad_aux=None, out=None, aux_is_deriv=False, c_colsum=None, c_colsum_accumulate=False):
     """dx[M,K] = dy2[M,N]·W with W given TRANSPOSED (wT [K,N]): both operands contraction-contiguous (fast path)"""
     M, N = dy2.shape
     K = wT.shape[0]
-    return gemm(dy2, wT, M, K, N, LAYOUT_KC, LAYOUT_KC, out=out, act=_dgrad_act(act_grad_aux, aux_is_deriv), aux_in=act_grad_aux)
+    return gemm(dy2, wT, M, K, N, LAYOUT_KC, LAYOUT_KC, out=out, act=_dgrad_act(act_grad_aux, aux_is_deriv), aux_in=act_grad_aux,
+                c_colsum=c_colsum, c_colsum_accumulate=c_colsum_accumulate)

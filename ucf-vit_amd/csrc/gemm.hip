@@ -380,6 +380,10 @@ extern "C" int ucfvit_gemm(const ucfvit_gemm_desc* d, void* stream) {
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;
     }
+    if (d->c_colsum_partial) {
+        ucfvit_set_error("ucfvit_gemm: c_colsum_partial is not available for this problem (ask ucfvit_gemm_colsum_rows first)");
+        return UCFVIT_ERR_UNSUPPORTED;
+    }
     EpiArgs ep;
     ep.bias = d->bias;
     ep.residual = d->residual;

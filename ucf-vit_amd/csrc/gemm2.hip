@@ -130,6 +130,7 @@ struct Epi2 {
     float* slab;       // split-K: fp32 partial matrices [splits][M][N] (ld = N); NULL when gridDim.y == 1
     unsigned long long* dbg;  // diagnostic stamps (UCFVIT_GEMM_DBG builds of the bench only); NULL in production
     int warm;          // 1: touch the C-shaped epilogue input during the K loop (UCFVIT_GEMM_WARM=0 disables, experiments)
+    float* cs_partial; // column sums of the output per 128-row block: [2 * tiles_m][N] (CS instantiations only), or NULL
 };
 
 // logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
@@ -490,7 +491,7 @@ struct Groups3 {
 // PD strips ahead with counted waits, its stores are never waited for.
 enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RESIDUAL = 2, EPI_GELU = 3, EPI_GELU_GRAD = 4, EPI_GELU_SAVE_DERIV = 5, EPI_MUL_AUX = 6 };
 
-template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC>
+template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false>
 __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, int k_per_split) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
@@ -708,6 +709,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #pragma unroll
                 for (int i = 0; i < PD; ++i) EPI_LOAD(i);
             }
+            float csum[8];          // CS: this lane's 8 columns summed over its 16 rows of the wave tile
+#pragma unroll
+            for (int r = 0; r < 8; ++r) csum[r] = 0.f;
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -775,6 +779,28 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, v[r]);
                     if (inside) *reinterpret_cast<Vec16<bf16>*>(C + (int64_t)m * ldc + n) = o;
+                    if constexpr (CS) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) csum[r] += inside ? v[r] : 0.f;
+                    }
+                }
+            }
+            if constexpr (CS) {
+                // lanes l, l+8, ..., l+56 hold the same 8 columns for different rows: xor-shuffle over lane bits 3..5, then lanes 0-7
+                // write the 64 column sums of this wave's 128 x 64 sub-tile (every [row block][column] entry is written exactly once)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float t = csum[r];
+                    t += __shfl_xor(t, 8, 64);
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    csum[r] = t;
+                }
+                const int n = n0 + wn + pcol;
+                if (prow == 0 && n < N) {
+                    float* cp = ep.cs_partial + (int64_t)((m0 >> 7) + grp) * N + n;
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+                    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
                 }
             }
 #undef EPI_LOAD
@@ -917,6 +943,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, OutT* __res
     }
 }
 
+static bool generic_epilogue_only();
+static bool pp_enabled();
+
 struct Plan2 {
     int big;     // 1: 256x256 tile, 0: 128x128
     int splits;
@@ -1038,10 +1067,10 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
     return UCFVIT_OK;
 }
 
-template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC>
+template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false>
 int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
     constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 8192;   // pipeline buffers + the cache-warming dump area
-    auto kern = gemm3_kernel<LA, LB, OutT, EPI>;
+    auto kern = gemm3_kernel<LA, LB, OutT, EPI, CS>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1083,12 +1112,7 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
     gt.total_tiles = gt.p[0].tiles_m * gt.p[0].tiles_n;
     if constexpr (LA == UCFVIT_LAYOUT_KC && LB == UCFVIT_LAYOUT_KC && sizeof(OutT) == 2) {
         // straight-line epilogues for the shapes of the training step (see EPI_* above); everything else is generic
-        static int generic_only = -1;
-        if (generic_only < 0) {
-            const char* e = getenv("UCFVIT_GEMM_GENERIC_EPI");   // experiments / A-B runs
-            generic_only = (e && e[0] == '1') ? 1 : 0;
-        }
-        if (!generic_only && p.splits == 1 && !ep.slab && !d->accumulate && d->N >= 8) {
+        if (!generic_epilogue_only() && p.splits == 1 && !ep.slab && !d->accumulate && d->N >= 8) {
             const int K_ = (int)d->K;
             if (ep.act == UCFVIT_ACT_NONE && !ep.residual && !ep.aux_out)
                 return launch3g<LA, LB, OutT, EPI_PLAIN>(gt, K_, ep, 1, p.k_per_split, s);
@@ -1100,11 +1124,22 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
                 return launch3g<LA, LB, OutT, EPI_GELU_GRAD>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV && !ep.residual)
                 return launch3g<LA, LB, OutT, EPI_GELU_SAVE_DERIV>(gt, K_, ep, 1, p.k_per_split, s);
-            if (ep.act == UCFVIT_ACT_MUL_AUX && !ep.residual && !ep.aux_out)
+            if (ep.act == UCFVIT_ACT_MUL_AUX && !ep.residual && !ep.aux_out) {
+                if (ep.cs_partial) return launch3g<LA, LB, OutT, EPI_MUL_AUX, true>(gt, K_, ep, 1, p.k_per_split, s);
                 return launch3g<LA, LB, OutT, EPI_MUL_AUX>(gt, K_, ep, 1, p.k_per_split, s);
+            }
         }
     }
     return launch3g<LA, LB, OutT>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
+}
+
+static bool generic_epilogue_only() {
+    static int flag = -1;
+    if (flag < 0) {
+        const char* e = getenv("UCFVIT_GEMM_GENERIC_EPI");   // experiments / A-B runs
+        flag = (e && e[0] == '1') ? 1 : 0;
+    }
+    return flag == 1;
 }
 
 static bool pp_enabled() {
@@ -1136,6 +1171,34 @@ int dispatch_layout2(const ucfvit_gemm_desc* d, const Plan2& p, const Epi2& ep, 
 
 }  // namespace
 
+// shape / alignment requirements of the DMA + vector-epilogue path (shared by ucfvit_gemm_v2_try and the by-product predicates)
+static bool v2_operands_ok(const ucfvit_gemm_desc* d) {
+    const int64_t a_contig = (d->a_layout == UCFVIT_LAYOUT_KC) ? d->K : d->M;
+    const int64_t b_contig = (d->b_layout == UCFVIT_LAYOUT_KC) ? d->K : d->N;
+    bool ok = ucf_is_aligned16(d->A) && ucf_is_aligned16(d->B) && d->lda % 8 == 0 && d->ldb % 8 == 0 && a_contig % 8 == 0 &&
+              b_contig % 8 == 0 && d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)d->C) % 16 == 0 && d->M < (1ll << 31) &&
+              d->N < (1ll << 31) && d->K < (1ll << 31);
+    if (d->bias) ok = ok && ((uintptr_t)d->bias) % 8 == 0;
+    if (d->residual) ok = ok && ((uintptr_t)d->residual) % 16 == 0 && d->ldr % 8 == 0;
+    if (d->aux_in) ok = ok && ((uintptr_t)d->aux_in) % 16 == 0 && d->ldaux % 8 == 0;
+    if (d->aux_out) ok = ok && ((uintptr_t)d->aux_out) % 16 == 0 && d->ldaux % 8 == 0;
+    return ok;
+}
+
+// the output column sums (desc->c_colsum_partial) exist in the specialised MUL_AUX epilogue of the 256x256 ping-pong kernel: the
+// data-gradient GEMM through the activation (C = dh of the MLP), two 128-row blocks per output tile row
+static int64_t colsum_rows_for(const ucfvit_gemm_desc* d) {
+    Plan2 p;
+    if (!d || !plan2(d, &p) || !v2_operands_ok(d)) return 0;
+    const int64_t a_bytes = d->M * d->lda * 2, b_bytes = d->N * d->ldb * 2;
+    const bool path = p.big && p.splits == 1 && pp_enabled() && !generic_epilogue_only() && a_bytes < (1ll << 32) && b_bytes < (1ll << 32) &&
+                      d->a_layout == UCFVIT_LAYOUT_KC && d->b_layout == UCFVIT_LAYOUT_KC && d->out_dtype == UCFVIT_BF16 && !d->accumulate &&
+                      d->N >= 8 && d->act == UCFVIT_ACT_MUL_AUX && !d->residual && !d->aux_out;
+    return path ? 2 * ((d->M + 255) / 256) : 0;
+}
+
+extern "C" int64_t ucfvit_gemm_colsum_rows(const ucfvit_gemm_desc* d) { return colsum_rows_for(d); }
+
 // bytes of fp32 workspace ucfvit_gemm wants for this problem (0 if none)
 extern "C" int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* d) {
     Plan2 p;
@@ -1147,18 +1210,7 @@ extern "C" int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* d) {
 int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     Plan2 p;
     if (!plan2(d, &p)) return 0;
-    // alignment / shape requirements of the DMA + vector-epilogue path
-    const int64_t a_contig = (d->a_layout == UCFVIT_LAYOUT_KC) ? d->K : d->M;
-    const int64_t b_contig = (d->b_layout == UCFVIT_LAYOUT_KC) ? d->K : d->N;
-    const size_t osz = d->out_dtype == UCFVIT_F32 ? 4 : 2;
-    bool ok = ucf_is_aligned16(d->A) && ucf_is_aligned16(d->B) && d->lda % 8 == 0 && d->ldb % 8 == 0 && a_contig % 8 == 0 &&
-              b_contig % 8 == 0 && d->N % 8 == 0 && d->ldc % 8 == 0 && ((uintptr_t)d->C) % 16 == 0 && d->M < (1ll << 31) &&
-              d->N < (1ll << 31) && d->K < (1ll << 31);
-    if (d->bias) ok = ok && ((uintptr_t)d->bias) % 8 == 0;
-    if (d->residual) ok = ok && ((uintptr_t)d->residual) % 16 == 0 && d->ldr % 8 == 0;
-    if (d->aux_in) ok = ok && ((uintptr_t)d->aux_in) % 16 == 0 && d->ldaux % 8 == 0;
-    if (d->aux_out) ok = ok && ((uintptr_t)d->aux_out) % 16 == 0 && d->ldaux % 8 == 0;
-    if (!ok) return 0;
+    if (!v2_operands_ok(d)) return 0;
     Epi2 ep;
     ep.bias = (const bf16*)d->bias;
     ep.residual = (const bf16*)d->residual;
@@ -1171,6 +1223,14 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     ep.accumulate = d->accumulate;
     ep.alpha = d->alpha;
     ep.slab = nullptr;
+    ep.cs_partial = nullptr;
+    if (d->c_colsum_partial) {
+        if (colsum_rows_for(d) == 0 || !ucf_is_aligned16(d->c_colsum_partial)) {
+            ucfvit_set_error("ucfvit_gemm: c_colsum_partial is not available for this problem (ask ucfvit_gemm_colsum_rows first)");
+            return UCFVIT_ERR_UNSUPPORTED;
+        }
+        ep.cs_partial = d->c_colsum_partial;
+    }
     {
         static int warm = -1;
         if (warm < 0) {

@@ -373,3 +373,12 @@ extern "C" int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, in
     UCF_LAUNCH_CHECK("ucfvit_colsum(reduce)");
     return UCFVIT_OK;
 }
+
+extern "C" int ucfvit_reduce_rows(const float* partial, float* out, int64_t rows, int64_t N, int accumulate, void* stream) {
+    UCF_CHECK_ARG(partial && out, "ucfvit_reduce_rows: null pointer");
+    UCF_CHECK_ARG(rows > 0 && N > 0 && rows < (1ll << 31) && N < (1ll << 31), "ucfvit_reduce_rows: bad shape");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + RP_COLS - 1) / RP_COLS)), dim3(256), 0, (hipStream_t)stream, partial, out,
+                       (float*)nullptr, (int)rows, (int)N, accumulate);
+    UCF_LAUNCH_CHECK("ucfvit_reduce_rows");
+    return UCFVIT_OK;
+}
