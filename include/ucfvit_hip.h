@@ -122,13 +122,16 @@ int ucfvit_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, 
  * x,y,dy,dx: [rows][D] dtype ; gamma,beta: [D] dtype ; mean,rstd: [rows] fp32 (saved for backward).
  * bwd: dx = LN-grad(dy) + dres (dres: optional [rows][D] dtype, the residual branch's gradient, fused; NULL = none);
  *      dgamma/dbeta are fp32 [D]; `accumulate` adds into them.  workspace: fp32, >= ucfvit_layernorm_bwd_workspace() bytes.
+ *      dx_colsum: optional fp32 [D] (+)= column sums of dx (taken in fp32 before rounding): dx is the gradient of the residual
+ *      stream, i.e. the output gradient of the proj / fc2 Linear before this norm, so this IS that layer's bias gradient and the
+ *      separate ucfvit_colsum pass over dx is not needed.  NULL = off.
  * ------------------------------------------------------------------------------------------------------ */
 int ucfvit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                          int64_t rows, int64_t D, float eps, int dtype, void* stream);
 int64_t ucfvit_layernorm_bwd_workspace(int64_t rows, int64_t D);
 int ucfvit_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                          const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, int accumulate,
-                         void* workspace, int dtype, void* stream);
+                         float* dx_colsum, int dx_colsum_accumulate, void* workspace, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused multi-head self-attention core, softmax(q·kᵀ·scale)·v, non-causal, no mask, dropout 0:

@@ -142,14 +142,59 @@ def _bgrad(bias, dy2):
     return None if acc else r
 
 
-def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None):
+def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None, dx_colsum=None, dx_colsum_accumulate=False):
     ow, aw = grad_target(weight)
     ob, ab = grad_target(bias)
     if aw != ab or (ow is None) != (ob is None):  # mixed states: take the simple route
         ow = ob = None
         aw = ab = False
-    dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma_c, mean, rstd, dres=dres, dgamma=ow, dbeta=ob, accumulate=aw)
+    dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma_c, mean, rstd, dres=dres, dgamma=ow, dbeta=ob, accumulate=aw, dx_colsum=dx_colsum,
+                                   dx_colsum_accumulate=dx_colsum_accumulate)
     return dx, (None if aw else dg), (None if ab else db)
+
+
+# The gradient of the residual stream leaves a LayerNorm backward (dx + dres) and is the output gradient of the Linear that wrote
+# into the stream before that norm: proj (inside the same Block) or fc2 (the Block before / the model's final norm).  Its column
+# sums = that Linear's bias gradient are taken by the LayerNorm-backward kernel; across autograd Functions they travel in this
+# one-slot cache, keyed by the tensor autograd hands on (held strongly until consumed or until backward ends, so its address
+# cannot be reused by another tensor in between).
+_STREAM_GRAD_COLSUM = [None]      # (dx tensor, fp32 [D] column sums)
+
+
+def _publish_stream_colsum(dx, cs):
+    _STREAM_GRAD_COLSUM[0] = (dx, cs)
+    if not _STREAM_GRAD_COLSUM_ARMED[0]:
+        _STREAM_GRAD_COLSUM_ARMED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_clear_stream_colsum)
+
+
+_STREAM_GRAD_COLSUM_ARMED = [False]
+
+
+def _clear_stream_colsum():
+    _STREAM_GRAD_COLSUM[0] = None
+    _STREAM_GRAD_COLSUM_ARMED[0] = False
+
+
+def _take_stream_colsum(dy2):
+    """column sums of dy2 if the LayerNorm backward that produced exactly this tensor published them, else None"""
+    ent = _STREAM_GRAD_COLSUM[0]
+    _STREAM_GRAD_COLSUM[0] = None
+    if ent is None or not _BIAS_FROM_EPILOGUE:
+        return None
+    dx, cs = ent
+    if dx.data_ptr() == dy2.data_ptr() and dx.numel() == dy2.numel() and dx.dtype == dy2.dtype and cs.numel() == dy2.shape[-1]:
+        return cs
+    return None
+
+
+def _bgrad_from(bias, cs):
+    """bias gradient from ready column sums (fp32 [D]): written / accumulated into the gradient target without touching dy"""
+    out, acc = grad_target(bias)
+    if out is None:
+        return cs
+    ops.reduce_rows(cs.view(1, -1), out, accumulate=acc)
+    return None if acc else out
 
 
 def _dgrad(dy2, p_w, w, aux=None, aux_is_deriv=False, c_colsum=None, c_colsum_accumulate=False):
@@ -218,12 +263,16 @@ def _attn_fwd(x2, B, N, H, wqkv, bqkv, wproj, bproj, residual, tp=None):
     return y, (qkv, o, lse)
 
 
-def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs, tp=None, wq=None):
+def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_projb, needs, tp=None, wq=None, projb_done=None):
+    """projb_done: (grad,) when the producer of dy2 (LayerNorm backward) has already written the proj bias gradient"""
     qkv, o, lse = saved
     dh = wproj.shape[0] // H
     H = H // tp.size if tp else H
     g_projw = _wgrad(p_projw, dy2, o, wq) if needs[2] else None
-    g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
+    if projb_done is not None:
+        g_projb = projb_done[0]
+    else:
+        g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
     do = _dgrad(dy2, p_projw, wproj)
     dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
     g_qkvw = _wgrad(p_qkvw, dqkv, x2, wq) if needs[0] else None
@@ -246,10 +295,14 @@ def _mlp_fwd(x2, w1, b1, w2, b2, residual, tp=None):
     return y, (h, a)
 
 
-def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=None):
+def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=None, dy2_colsum=None):
+    """dy2_colsum: column sums of dy2 when its producer (a LayerNorm backward) published them: the fc2 bias gradient"""
     h, a = saved
     g_w2 = _wgrad(p_w2, dy2, a, wq) if needs[2] else None
-    g_b2 = _bgrad(p_b2, dy2) if (p_b2 is not None and needs[3]) else None
+    if p_b2 is not None and needs[3]:
+        g_b2 = _bgrad_from(p_b2, dy2_colsum) if dy2_colsum is not None else _bgrad(p_b2, dy2)
+    else:
+        g_b2 = None
     # dgrad fused with gelu'(pre-activation); the fc1 bias gradient = column sums of dh comes out of the same epilogue
     need_b1 = p_b1 is not None and needs[1]
     if need_b1 and _BIAS_FROM_EPILOGUE:
@@ -310,7 +363,10 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, mean, rstd, weight, bias = ctx.saved_tensors
         dy2 = _as(dy, ctx.cdtype).reshape(x2.shape)
-        dx, dg, db = _ln_bwd(dy2, x2, compute_param(weight, ctx.cdtype), mean, rstd, weight, bias)
+        cs = torch.empty(x2.shape[1], dtype=torch.float32, device=dy2.device) if (_BIAS_FROM_EPILOGUE and ctx.in_dtype == ctx.cdtype) else None
+        dx, dg, db = _ln_bwd(dy2, x2, compute_param(weight, ctx.cdtype), mean, rstd, weight, bias, dx_colsum=cs)
+        if cs is not None:
+            _publish_stream_colsum(dx, cs)      # e.g. the model's final norm: its dx is the last Block's output gradient
         return _ret_grad(dx.view(ctx.in_shape), ctx.in_dtype), dg, db, None, None
 
 
@@ -390,10 +446,24 @@ class BlockFn(torch.autograd.Function):
         c = lambda p: compute_param(p, cdtype)
         dy2 = _as(dy, cdtype).reshape(x2.shape)
         wq = _WQ
-        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq)
-        dx1, g_n2w, g_n2b = _ln_bwd(dln2, x1, c(n2w), mean2, rstd2, n2w, n2b, dres=dy2)        # + residual branch
-        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7], tp, wq)
-        dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1)
+        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq, dy2_colsum=_take_stream_colsum(dy2))
+        # LayerNorm backward also sums its output (the residual-stream gradient) over the tokens: proj's bias gradient here ...
+        projb_done = None
+        pb_out, pb_acc = None, False
+        if _BIAS_FROM_EPILOGUE and projb is not None and need[6]:
+            pb_out, pb_acc = grad_target(projb)
+            if pb_out is None:
+                pb_out = torch.empty(projb.shape, dtype=torch.float32, device=dy2.device)
+            projb_done = (None if pb_acc else pb_out,)
+        dx1, g_n2w, g_n2b = _ln_bwd(dln2, x1, c(n2w), mean2, rstd2, n2w, n2b, dres=dy2, dx_colsum=pb_out,       # + residual branch
+                                    dx_colsum_accumulate=pb_acc)
+        dln1, ga = _attn_bwd(dx1, ln1, (qkv, o, lse), B, N, H, c(qkvw), c(projw), qkvw, qkvb, projw, projb, need[3:7], tp, wq,
+                             projb_done=projb_done)
+        # ... and, published for whoever receives dx, the fc2 bias gradient of the Block before this one
+        cs0 = torch.empty(x2.shape[1], dtype=torch.float32, device=dy2.device) if _BIAS_FROM_EPILOGUE else None
+        dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1, dx_colsum=cs0)
+        if cs0 is not None and in_dtype == cdtype:
+            _publish_stream_colsum(dx, cs0)
         wq.end_block()                                   # the Block's 4 weight gradients: grouped launch now, or with the next Blocks'
         return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None)
 

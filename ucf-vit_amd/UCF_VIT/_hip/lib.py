@@ -46,7 +46,7 @@ SIGNATURES = {
     "ucfvit_colsum": (c_int, [_P, _P, _I64, _I64, _I64, _I, _P, _I, _P]),
     "ucfvit_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P]),
     "ucfvit_layernorm_bwd_workspace": (c_int64, [_I64, _I64]),
-    "ucfvit_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _I, _P]),
+    "ucfvit_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _I, _P, _I, _P]),
     "ucfvit_attention_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_im2col": (c_int, [_P, _P, _I64, _I64, POINTER(c_int64), _I, _I64, _I, _P]),

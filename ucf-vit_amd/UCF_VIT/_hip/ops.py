@@ -155,6 +155,14 @@ def linear_wgrad(dy2, x2, out=None, accumulate=False):
     return gemm(dy2, x2, N, K, M, LAYOUT_KS, LAYOUT_KS, out=out, out_dtype=torch.float32, accumulate=accumulate)
 
 
+def reduce_rows(partial, out, accumulate=False):
+    """out[N] (+)= sum over the rows of partial [R, N] (fp32)"""
+    L = _l.load()
+    R, N = partial.shape
+    _l.check(L.ucfvit_reduce_rows(partial.data_ptr(), out.data_ptr(), R, N, 1 if accumulate else 0, _stream()), "ucfvit_reduce_rows")
+    return out
+
+
 def colsum(x2, out=None, accumulate=False):
     L = _l.load()
     _chk(x2, "colsum.x")
@@ -180,7 +188,9 @@ def layernorm_fwd(x2, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False):
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, accumulate=False, dx_colsum=None,
+                  dx_colsum_accumulate=False):
+    """-> dx, dgamma, dbeta; dx_colsum: optional fp32 [D] that receives (+)= the column sums of dx (a bias gradient, see the header)"""
     L = _l.load()
     _chk(dy2, "layernorm_bwd.dy")
     rows, D = x2.shape
@@ -192,7 +202,8 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None
     ws = workspace(L.ucfvit_layernorm_bwd_workspace(rows, D), x2.device)
     _l.check(L.ucfvit_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres),
                                     dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, 1 if accumulate else 0,
-                                    ws.data_ptr(), dt(x2), _stream()), "ucfvit_layernorm_bwd")
+                                    _p(dx_colsum), 1 if dx_colsum_accumulate else 0, ws.data_ptr(), dt(x2), _stream()),
+             "ucfvit_layernorm_bwd")
     return dx, dgamma, dbeta
 
 

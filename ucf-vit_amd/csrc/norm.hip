@@ -66,7 +66,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const T* __restrict_
 
 // ---------------------------------------------------------------------------------------------------
 // backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma ; per-workgroup partial dgamma/dbeta
-template <typename T, int NV>
+// DXS: also the column sums of dx (+ dres) = the bias gradient of the Linear layer that produced LayerNorm's input's residual
+// partner (proj / fc2 of the Block before): third row of the per-workgroup partials
+template <typename T, int NV, bool DXS>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -75,11 +77,15 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
     __shared__ float red[4][64 * 8 + 8];  // cross-wave reduction staging, one 16-B vector slot (as fp32 x EPV) at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D / EPV;
-    float dg[NV][EPV], db[NV][EPV];
+    float dg[NV][EPV], db[NV][EPV], dxs[DXS ? NV : 1][EPV];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < EPV; ++e) dg[i][e] = db[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (DXS ? NV : 1); ++i)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) dxs[i][e] = 0.f;
     Vec16<T> gv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -122,28 +128,29 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
                     float r = rs * (g - c1 - xh * c2);
                     if (dres) r += rv.get(e);  // fused residual-branch gradient
                     o.set(e, r);
+                    if constexpr (DXS) dxs[i][e] += r;
                 }
                 *reinterpret_cast<Vec16<T>*>(dx + row * D + v * EPV) = o;
             }
         }
     }
-    // reduce the 4 waves' column partials through LDS, then one row of `partial` per workgroup: [grid][2][D]
-    float* pg = partial + (int64_t)blockIdx.x * 2 * D;
-    float* pb = pg + D;
+    // reduce the 4 waves' column partials through LDS, then one row of `partial` per workgroup: [grid][2 or 3][D]
+    constexpr int NOUT = DXS ? 3 : 2;
+    float* pg = partial + (int64_t)blockIdx.x * NOUT * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = lane + 64 * i;
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < NOUT; ++which) {
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) red[wave][lane * EPV + e] = which ? db[i][e] : dg[i][e];
+            for (int e = 0; e < EPV; ++e) red[wave][lane * EPV + e] = which == 0 ? dg[i][e] : (which == 1 ? db[i][e] : dxs[DXS ? i : 0][e]);
             __syncthreads();
             if (wave == 0 && v < nvec) {
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
                     const float t = red[0][lane * EPV + e] + red[1][lane * EPV + e] + red[2][lane * EPV + e] + red[3][lane * EPV + e];
-                    (which ? pb : pg)[v * EPV + e] = t;
+                    pg[which * D + v * EPV + e] = t;
                 }
             }
         }
@@ -155,12 +162,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
 // many short threads rather than few long ones (measured 13.6 us per launch at 32 x 8, 147 launches per ViT-L step).
 constexpr int RP_COLS = 16, RP_GROUPS = 16;
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out0,
-                                                              float* __restrict__ out1, int nblocks, int W0, int accumulate) {
-    // partial rows are [2][W0]: first W0 -> out0, next W0 -> out1 (out1 may be NULL: then rows are [1][W0])
+                                                              float* __restrict__ out1, int nblocks, int W0, int accumulate,
+                                                              float* __restrict__ out2 = nullptr, int accumulate2 = 0) {
+    // partial rows are [1, 2 or 3][W0]: first W0 -> out0, next W0 -> out1, last W0 -> out2 (NULL outputs end the row)
     __shared__ float red[RP_GROUPS][RP_COLS + 1];
     const int cl = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
     const int j = blockIdx.x * RP_COLS + cl;
-    const int W = out1 ? 2 * W0 : W0;
+    const int W = out2 ? 3 * W0 : (out1 ? 2 * W0 : W0);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (j < W) {
         const float* p = partial + j;
@@ -179,8 +187,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < RP_GROUPS; ++k) t += red[k][cl];
-        float* o = (j < W0) ? (out0 + j) : (out1 + (j - W0));
-        *o = accumulate ? (*o + t) : t;
+        float* o = (j < W0) ? (out0 + j) : (j < 2 * W0 ? out1 + (j - W0) : out2 + (j - 2 * W0));
+        const int acc = j < 2 * W0 ? accumulate : accumulate2;
+        *o = acc ? (*o + t) : t;
     }
 }
 
@@ -283,15 +292,21 @@ int ln_fwd_t(const void* x, const void* gamma, const void* beta, void* y, float*
 
 template <typename T>
 int ln_bwd_t(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
-             float* dbeta, int64_t rows, int64_t D, int accumulate, void* ws, hipStream_t s) {
+             float* dbeta, int64_t rows, int64_t D, int accumulate, float* dx_colsum, int dx_colsum_accumulate, void* ws, hipStream_t s) {
     const int nv = ln_nv<T>(D);
     UCF_CHECK_ARG(nv > 0 && nv <= 4, "ucfvit_layernorm_bwd: D=%lld must be a multiple of %d and <= %d", (long long)D,
                   (int)(16 / sizeof(T)), (int)(256 * 16 / sizeof(T)));
     const int g = ln_grid(rows);
     const dim3 grid(g), block(LN_THREADS);
-#define LN_BWD(NVV)                                                                                                       \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)gamma, mean, rstd, \
-                       (const T*)dres, (T*)dx, (float*)ws, rows, (int)D)
+#define LN_BWD(NVV)                                                                                                            \
+    do {                                                                                                                       \
+        if (dx_colsum)                                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, true>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)gamma, mean, rstd, \
+                               (const T*)dres, (T*)dx, (float*)ws, rows, (int)D);                                             \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((ln_bwd_kernel<T, NVV, false>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)gamma, mean, rstd, \
+                               (const T*)dres, (T*)dx, (float*)ws, rows, (int)D);                                             \
+    } while (0)
     switch (nv) {
         case 1: LN_BWD(1); break;
         case 2: LN_BWD(2); break;
@@ -299,9 +314,9 @@ int ln_bwd_t(const void* dy, const void* x, const void* gamma, const float* mean
     }
 #undef LN_BWD
     UCF_LAUNCH_CHECK("ucfvit_layernorm_bwd");
-    const int W = 2 * (int)D;
+    const int W = (dx_colsum ? 3 : 2) * (int)D;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((W + RP_COLS - 1) / RP_COLS), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, g, (int)D,
-                       accumulate);
+                       accumulate, dx_colsum, dx_colsum_accumulate);
     UCF_LAUNCH_CHECK("ucfvit_layernorm_bwd(reduce)");
     return UCFVIT_OK;
 }
@@ -322,20 +337,22 @@ extern "C" int ucfvit_layernorm_fwd(const void* x, const void* gamma, const void
 }
 
 extern "C" int64_t ucfvit_layernorm_bwd_workspace(int64_t rows, int64_t D) {
-    return (int64_t)ln_grid(rows) * 2 * D * (int64_t)sizeof(float);
+    return (int64_t)ln_grid(rows) * 3 * D * (int64_t)sizeof(float);      // dgamma, dbeta and (optional) dx column-sum partials
 }
 
 extern "C" int ucfvit_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                                     const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t D, int accumulate,
-                                    void* workspace, int dtype, void* stream) {
+                                    float* dx_colsum, int dx_colsum_accumulate, void* workspace, int dtype, void* stream) {
     UCF_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "ucfvit_layernorm_bwd: null pointer");
     UCF_CHECK_ARG(rows > 0 && D > 0, "ucfvit_layernorm_bwd: bad shape");
     UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(dy) && ucf_is_aligned16(dx) && ucf_is_aligned16(gamma) && ucf_is_aligned16(dres),
                   "ucfvit_layernorm_bwd: pointers must be 16-byte aligned");
     if (dtype == UCFVIT_F32)
-        return ln_bwd_t<float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, accumulate, workspace, (hipStream_t)stream);
+        return ln_bwd_t<float>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, accumulate, dx_colsum, dx_colsum_accumulate, workspace,
+                               (hipStream_t)stream);
     if (dtype == UCFVIT_BF16)
-        return ln_bwd_t<bf16>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, accumulate, workspace, (hipStream_t)stream);
+        return ln_bwd_t<bf16>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, accumulate, dx_colsum, dx_colsum_accumulate, workspace,
+                              (hipStream_t)stream);
     ucfvit_set_error("ucfvit_layernorm_bwd: bad dtype %d", dtype);
     return UCFVIT_ERR_UNSUPPORTED;
 }
