@@ -625,6 +625,113 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
     }
 }
 
+
+// =====================================================================================================================
+// forward, bf16 head dim 64, three workgroups per CU: the resident forward above with (i) images of exactly 16 NB rows, V FIRST
+// and K behind it — the transposed V reads of the last 32-row chunk run up to 16 rows past V's end, i.e. into K's first rows,
+// which are finite numbers multiplied by P = 0 — so a workgroup needs 2 x 26 KiB of LDS and three fit a CU (159,744 of 163,840 B);
+// (ii) the six-base addressing and sched_barriers of the fused backward, which bring it under the 170 VGPRs three waves per SIMD
+// allow.  One more workgroup per CU = one more head's loads in flight behind the MFMA / softmax work of the other two.
+// =====================================================================================================================
+template <int NB, bool EXACT>
+__global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+                                                                     int N, int H, float scale_log2e) {
+    typedef bf16 T;
+    constexpr int DH = 64, NDB = 4, NRC = (NB + 1) / 2, ROWS = NB * 16, IMG = ROWS * 128;
+    static_assert(NRC * 32 - ROWS <= 16, "the last transposed chunk may only run into K's first 16 rows");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsV = smem;
+    char* ldsK = smem + IMG;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x % H;
+    const int64_t b = blockIdx.x / H;
+    const int D = H * DH;
+    const int64_t rs = 3 * (int64_t)D;
+    const T* qbase = qkv + b * N * rs + h * DH;
+    {
+        AgStage<ROWS> sk, sv;
+        ag_fetch<ROWS>(sk, qbase + D, rs, N, tid);
+        ag_fetch<ROWS>(sv, qbase + 2 * D, rs, N, tid);
+        ag_store<ROWS>(sk, ldsK, tid);
+        ag_store<ROWS>(sv, ldsV, tid);
+    }
+    __syncthreads();
+    const int rowb0 = li * 128 + ((g ^ (li & 7)) << 4), rowb1 = rowb0 ^ 64;
+    const int tq = li >> 2, tp = li & 3;
+    const int trb = (4 * g + tq) * 128 + ((((tp >> 1) ^ (4 * (g & 1) + tq))) << 4) + (tp & 1) * 8;
+    constexpr int nb_ = NB;
+    const int nqb = (N + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += AG_WAVES) {
+        const int q = qb * 16 + li;
+        const bf16x8 qf0 = s_frag_global<T, DH>(qbase, rs, q, N, 0, lane), qf1 = s_frag_global<T, DH>(qbase, rs, q, N, 1, lane);
+        f32x4 s[NB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            MmaS<T>::mma(s[kb], af_row(ldsK, rowb0, kb), qf0);
+            MmaS<T>::mma(s[kb], af_row(ldsK, rowb1, kb), qf1);
+            if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) {   // only the ragged / padding key blocks pay for masking
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kb][r] = (kb * 16 + 4 * g + r < N) ? s[kb][r] : -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][r]);
+            if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float m = gmax(mx) * scale_log2e;
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m));
+                s[kb][r] = p;
+                l += p;
+            }
+        const float lt = gsum(l);
+        f32x4 o[NDB];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rc = 0; rc < NRC; ++rc) {
+            const bf16x8 pf = s_frag_acc<T, nb_>(s, rc);
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(o[d], af_tr(ldsV, trb ^ (d << 5), rc), pf);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < N) {
+            const float inv = 1.f / lt;
+            T* op = out + (b * N + q) * D + h * DH;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                Vec4<T> v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v.set(r, o[d][r] * inv);
+                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            }
+            if (g == 0) lse[(b * H + h) * N + q] = m + log2f(lt);
+        }
+    }
+}
+
+template <int NB>
+int launch_s3_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+    constexpr size_t smem = 2 * (size_t)NB * 16 * 128;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const dim3 grid((unsigned)(B * H)), block(AG_THREADS);
+    if ((N + 15) / 16 == NB) {
+        if (int rc = big_lds(attn_s3_fwd_kernel<NB, true>, smem)) return rc;
+        hipLaunchKernelGGL((attn_s3_fwd_kernel<NB, true>), grid, block, smem, s, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, sl2);
+    } else {
+        if (int rc = big_lds(attn_s3_fwd_kernel<NB, false>, smem)) return rc;
+        hipLaunchKernelGGL((attn_s3_fwd_kernel<NB, false>), grid, block, smem, s, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, sl2);
+    }
+    UCF_LAUNCH_CHECK("ucfvit_attention_fwd(short, 3 per CU)");
+    return UCFVIT_OK;
+}
+
 template <int NB>
 int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
     constexpr int ROWS = ((NB + 1) / 2) * 32;
@@ -660,6 +767,8 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
     // bf16 only: the fp32 instantiations exceed the register file (the exact-fp32 parity mode keeps the streaming kernels)
     if (dtype != UCFVIT_BF16 || N > 256 || (dh != 32 && dh != 64) || B * H >= (1ll << 31)) return 0;
     const int nb = (int)((N + 15) / 16);
+    static const bool s3 = [] { const char* e = getenv("UCFVIT_ATTN_FWD_S3"); return !(e && e[0] == '0'); }();
+    if (s3 && dh == 64 && nb > 8 && nb <= 13) return launch_s3_fwd<13>(qkv, out, lse, B, N, H, scale, s) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;
     if (dh == 64) AS_PICK(launch_fwd, bf16, 64, qkv, out, lse, B, N, H, scale, s);
     AS_PICK(launch_fwd, bf16, 32, qkv, out, lse, B, N, H, scale, s);
 }
