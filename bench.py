@@ -92,16 +92,17 @@ class GemmProfiler:
 
 
 def pmc_traffic(workload, dtype, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, profiles/r01_pmc_traffic_*.json) — counters cannot be read from inside the process; null if no matching profile."""
+    """HBM bytes per launch of the dominant kernel (average over every gemm3_kernel launch of the step) from the committed rocprofv3
+    PMC passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, newest profiles/*pmc_traffic*.json whose
+    workload / dtype / batch match) — counters cannot be read from inside the process; null if no matching profile."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(f))
             if d.get("workload") == workload and d.get("dtype") == dtype and d.get("per_gpu_batch") == batch:
-                for k, v in d["kernels"].items():
-                    if k.startswith("gemm3"):
-                        return round(v["hbm_bytes_per_launch_corrected"])
+                k = d["kernels"]
+                if "ALL gemm3_kernel launches" in k:
+                    return round(k["ALL gemm3_kernel launches"]["hbm_bytes_per_launch_corrected"])
         except Exception:
             pass
     return None
