@@ -119,6 +119,46 @@ def test_adamw_trajectory_vs_reference():
         assert rel_err(v, ref) < 1e-3, k
 
 
+def test_bf16_loss_curve_tracks_cpu_reference():
+    """BASELINE north_star: 'loss-curve-equivalent to the CPU reference'.  40 optimiser steps of the classification loop (reference
+    order, train_class_simple.py:344-357) on a fixed cycle of 4 synthetic batches: the bf16 HIP path (fast-GELU epilogues, saved
+    gelu', fused attention, grouped weight gradients, by-product bias gradients, fused AdamW) against the fp32 CPU oracle from the
+    same deterministic initialisation.  Tolerance: every loss within 4 % (+0.02 absolute) of the oracle's (measured: < 0.1 %),
+    and both curves must go down (random labels: final loss below 97 % of the first)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ucf_vit_ref as R
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
+    kw = dict(img_size=[32, 32], patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=3, num_heads=2)
+    m = build(VIT, kw, 77, torch.bfloat16)
+    ref = R.VIT(kw["img_size"], patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=3, num_heads=2, sdpa=True)
+    ref.load_state_dict(det_state_dict(ref, 77))
+    opt = configure_optimizer(m, 2e-3, 0.9, 0.95, 1e-2)
+    sch = configure_scheduler(opt, 5, 40, 1e-5, 1e-6)
+    ropt = R.configure_optimizer(ref, 2e-3, 0.9, 0.95, 1e-2)
+    rsch = R.WarmupCosineLR(ropt, 5, 40, 1e-5, 1e-6)
+    gen = torch.Generator().manual_seed(123)
+    xs = [torch.rand(16, 3, 32, 32, generator=gen) for _ in range(4)]
+    ys = [torch.randint(0, 5, (16,), generator=gen) for _ in range(4)]
+    got, want = [], []
+    for i in range(40):
+        x, y = xs[i % 4], ys[i % 4]
+        loss = cross_entropy_loss(m(x.to(DEV), VARS), y.to(DEV))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        sch.step()
+        got.append(loss.item())
+        rl, _ = R.train_step_class(ref, ropt, rsch, x, y)
+        want.append(rl.item())
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert abs(a - b) <= 0.04 * abs(b) + 0.02, (i, a, b)
+    assert got[-1] < 0.97 * got[0] and want[-1] < 0.97 * want[0], (got[0], got[-1], want[0], want[-1])
+
+
 def test_bf16_shadow_follows_master():
     from UCF_VIT.simple.arch import VIT
     from UCF_VIT.utils.metrics import cross_entropy_loss
