@@ -1080,7 +1080,16 @@ int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_spl
         }
         done = true;
     }
-    int cap = 256 / splits;
+    // persistent grid = the CUs this launch may count on.  One 512-thread workgroup fills a CU's register file, so a CU that hosts a
+    // wave of another kernel (an RCCL all-reduce overlapping backward) cannot take one: a grid larger than the free CUs leaves
+    // workgroups waiting for a whole tile list.  UCFVIT_GEMM_CUS (default 256) lets a multi-GPU job reserve the CUs RCCL uses.
+    static int cus = 0;
+    if (!cus) {
+        const char* e = getenv("UCFVIT_GEMM_CUS");
+        cus = e ? atoi(e) : 256;
+        if (cus < 8 || cus > 256) cus = 256;
+    }
+    int cap = cus / splits;
     if (cap < 1) cap = 1;
     const int gx = gt.total_tiles < cap ? gt.total_tiles : cap;
     hipLaunchKernelGGL(kern, dim3(gx, splits), dim3(512), smem, s, gt, K, ep, k_per_split);
