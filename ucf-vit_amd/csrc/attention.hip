@@ -20,8 +20,6 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
                                hipStream_t s);
 int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
                                float scale, int dtype, hipStream_t s);
-int ucfvit_attention_short_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
-                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s);
 
 static bool short_enabled() {
     static int flag = -1;
@@ -513,13 +511,6 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
     hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, B,
                        (int)N, (int)H);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");
-    // measured (ViT-L, N=197, B=166): the two-kernel resident backward (541 us) is slower than the streaming pair (430 us)
-    static const bool short_bwd = [] { const char* e = getenv("UCFVIT_ATTN_SHORT_BWD"); return e && e[0] == '1'; }();
-    if (short_enabled() && short_bwd) {
-        const int rc = ucfvit_attention_short_bwd(qkv, dout, lse, delta, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
-        if (rc == 1) return UCFVIT_OK;
-        if (rc < 0) return rc;
-    }
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)H, (unsigned)B);
     const float sl2 = scale * 1.44269504088896340736f;
     constexpr size_t smem_dq = 2 * AT<T, DH>::TILE_BYTES;

@@ -1,7 +1,7 @@
 // Short-sequence fused attention for gfx950 (N <= 256 tokens: ViT 224^2/16 has N = 197, MAE encoder 49, MAE decoder 196).
 //
-// One workgroup per (batch, head): the whole K and V (forward, dQ) or Q and dO (dK/dV) of that head live in LDS for the
-// lifetime of the workgroup — they are read from HBM/L2 once instead of once per 64-query tile — and the softmax is single
+// One workgroup per (batch, head): the whole K and V (forward, backward phase A) or Q and dO (backward phase B) of that head live
+// in LDS — they are read from HBM/L2 once instead of once per 64-query tile — and the softmax is single
 // pass (all scores of a query row are in registers at once: no running max, no rescaling of the output accumulator).
 // Work is cut in 16-row MFMA blocks, so N = 197 costs 13 x 13 blocks (208^2) instead of the 4 x 4 tiles of 64 (256^2) of the
 // streaming kernel.  Same "softmax index on the lane" layout as attention.hip: Sᵀ[key][q] = K·Qᵀ, accumulators feed the
@@ -207,166 +207,6 @@ __global__ __launch_bounds__(AS_THREADS) void attn_s_fwd_kernel(const T* __restr
     }
 }
 
-// =====================================================================================================================
-// backward dQ: K, V resident; wave handles query blocks
-// =====================================================================================================================
-template <typename T, int DH, int NB, bool EXACT>
-__global__ __launch_bounds__(AS_THREADS) void attn_s_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-                                                                const float* __restrict__ delta, T* __restrict__ dqkv, int N, int H, float scale,
-                                                                float scale_log2e) {
-    typedef AS<T, DH, NB> A;
-    typedef typename A::frag_t frag_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsK = smem;
-    char* ldsV = smem + A::IMG;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x % H;
-    const int64_t b = blockIdx.x / H;
-    const int D = H * DH;
-    const int64_t rs = 3 * (int64_t)D;
-    const T* qbase = qkv + b * N * rs + h * DH;
-    const T* dobase = dout + b * N * (int64_t)D + h * DH;
-    load_image<T, DH, A::ROWS>(ldsK, qbase + D, rs, N, tid);
-    load_image<T, DH, A::ROWS>(ldsV, qbase + 2 * D, rs, N, tid);
-    __syncthreads();
-    const int nqb = (N + 15) / 16;
-    for (int qb = wave; qb < nqb; qb += 4) {
-        const int q = qb * 16 + li;
-        frag_t qf[A::NCH], dof[A::NCH];
-#pragma unroll
-        for (int c = 0; c < A::NCH; ++c) {
-            qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
-            dof[c] = s_frag_global<T, DH>(dobase, D, q, N, c, lane);
-        }
-        const float my_lse = q < N ? lse[(b * H + h) * N + q] : 0.f;
-        const float my_delta = q < N ? delta[(b * H + h) * N + q] : 0.f;
-        f32x4 ds[NB];
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < A::NCH; ++c) {
-                MmaS<T>::mma(s, s_frag_row<T, DH>(ldsK, kb, c, lane), qf[c]);
-                MmaS<T>::mma(dp, s_frag_row<T, DH>(ldsV, kb, c, lane), dof[c]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -my_lse));
-                if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) p = (kb * 16 + 4 * g + r < N) ? p : 0.f;     // ragged key block only
-                ds[kb][r] = p * (dp[r] - my_delta);
-            }
-        }
-        f32x4 dq[A::NDB];
-#pragma unroll
-        for (int d = 0; d < A::NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int rc = 0; rc < A::NRC; ++rc) {
-            const frag_t f = s_frag_acc<T, NB>(ds, rc);
-#pragma unroll
-            for (int d = 0; d < A::NDB; ++d) MmaS<T>::mma(dq[d], s_frag_tr<T, DH>(ldsK, rc, d, lane), f);
-        }
-        if (q < N) {
-            T* op = dqkv + (b * N + q) * rs + h * DH;
-#pragma unroll
-            for (int d = 0; d < A::NDB; ++d) {
-                Vec4<T> v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v.set(r, dq[d][r] * scale);
-                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
-            }
-        }
-    }
-}
-
-// =====================================================================================================================
-// backward dK / dV: Q, dO (+ lse, delta) resident; wave handles key blocks
-// =====================================================================================================================
-template <typename T, int DH, int NB>
-__global__ __launch_bounds__(AS_THREADS) void attn_s_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-                                                                 const float* __restrict__ delta, T* __restrict__ dqkv, int N, int H, float scale,
-                                                                 float scale_log2e) {
-    typedef AS<T, DH, NB> A;
-    typedef typename A::frag_t frag_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsQ = smem;
-    char* ldsDO = smem + A::IMG;
-    float* ldsLse = reinterpret_cast<float*>(smem + 2 * A::IMG);   // [ROWS]
-    float* ldsDelta = ldsLse + A::ROWS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.x % H;
-    const int64_t b = blockIdx.x / H;
-    const int D = H * DH;
-    const int64_t rs = 3 * (int64_t)D;
-    const T* qbase = qkv + b * N * rs + h * DH;
-    const T* dobase = dout + b * N * (int64_t)D + h * DH;
-    load_image<T, DH, A::ROWS>(ldsQ, qbase, rs, N, tid);
-    load_image<T, DH, A::ROWS>(ldsDO, dobase, D, N, tid);
-    for (int i = tid; i < A::ROWS; i += AS_THREADS) {
-        ldsLse[i] = i < N ? lse[(b * H + h) * N + i] : INFINITY;    // +inf -> P = 0 for padding queries
-        ldsDelta[i] = i < N ? delta[(b * H + h) * N + i] : 0.f;
-    }
-    __syncthreads();
-    const int nkb = (N + 15) / 16;
-    for (int kb = wave; kb < nkb; kb += 4) {
-        const int key = kb * 16 + li;
-        frag_t kf[A::NCH], vf[A::NCH];
-#pragma unroll
-        for (int c = 0; c < A::NCH; ++c) {
-            kf[c] = s_frag_global<T, DH>(qbase + D, rs, key, N, c, lane);
-            vf[c] = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, c, lane);
-        }
-        f32x4 pm[NB], ds[NB];
-#pragma unroll
-        for (int qb = 0; qb < NB; ++qb) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < A::NCH; ++c) {
-                MmaS<T>::mma(s, s_frag_row<T, DH>(ldsQ, qb, c, lane), kf[c]);
-                MmaS<T>::mma(dp, s_frag_row<T, DH>(ldsDO, qb, c, lane), vf[c]);
-            }
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsLse + qb * 16 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -l4[r]));
-                pm[qb][r] = p;
-                ds[qb][r] = p * (dp[r] - d4[r]);
-            }
-        }
-        f32x4 dk[A::NDB], dv[A::NDB];
-#pragma unroll
-        for (int d = 0; d < A::NDB; ++d) {
-            dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int rc = 0; rc < A::NRC; ++rc) {
-            const frag_t fp = s_frag_acc<T, NB>(pm, rc);
-            const frag_t fs = s_frag_acc<T, NB>(ds, rc);
-#pragma unroll
-            for (int d = 0; d < A::NDB; ++d) {
-                MmaS<T>::mma(dv[d], s_frag_tr<T, DH>(ldsDO, rc, d, lane), fp);
-                MmaS<T>::mma(dk[d], s_frag_tr<T, DH>(ldsQ, rc, d, lane), fs);
-            }
-        }
-        if (key < N) {
-            T* kp = dqkv + (b * N + key) * rs + D + h * DH;
-            T* vp = kp + D;
-#pragma unroll
-            for (int d = 0; d < A::NDB; ++d) {
-                Vec4<T> a, c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    a.set(r, dk[d][r] * scale);
-                    c.set(r, dv[d][r]);
-                }
-                *reinterpret_cast<Vec4<T>*>(kp + d * 16 + 4 * g) = a;
-                *reinterpret_cast<Vec4<T>*>(vp + d * 16 + 4 * g) = c;
-            }
-        }
-    }
-}
-
 template <typename K> int big_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return UCFVIT_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -392,30 +232,6 @@ int launch_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int
     UCF_LAUNCH_CHECK("ucfvit_attention_fwd(short)");
     return UCFVIT_OK;
 }
-template <typename T, int DH, int NB>
-int launch_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N, int64_t H, float scale,
-               hipStream_t s) {
-    constexpr size_t smem_dq = 2 * AS<T, DH, NB>::IMG;
-    constexpr size_t smem_dkv = smem_dq + 2 * AS<T, DH, NB>::ROWS * sizeof(float);
-    if (int rc = big_lds(attn_s_dkv_kernel<T, DH, NB>, smem_dkv)) return rc;
-    const float sl2 = scale * 1.44269504088896340736f;
-    if ((N + 15) / 16 == NB) {
-        if (int rc = big_lds(attn_s_dq_kernel<T, DH, NB, true>, smem_dq)) return rc;
-        hipLaunchKernelGGL((attn_s_dq_kernel<T, DH, NB, true>), dim3((unsigned)(B * H)), dim3(AS_THREADS), smem_dq, s, (const T*)qkv, (const T*)dout, lse,
-                           delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
-    } else {
-        if (int rc = big_lds(attn_s_dq_kernel<T, DH, NB, false>, smem_dq)) return rc;
-        hipLaunchKernelGGL((attn_s_dq_kernel<T, DH, NB, false>), dim3((unsigned)(B * H)), dim3(AS_THREADS), smem_dq, s, (const T*)qkv, (const T*)dout, lse,
-                           delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
-    }
-    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(short dq)");
-    hipLaunchKernelGGL((attn_s_dkv_kernel<T, DH, NB>), dim3((unsigned)(B * H)), dim3(AS_THREADS), smem_dkv, s, (const T*)qkv, (const T*)dout, lse,
-                       delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
-    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(short dkv)");
-    return UCFVIT_OK;
-}
-
-
 // =====================================================================================================================
 // backward, fused (bf16, head dim 64, N <= 208): ONE launch per attention layer instead of delta + dQ + dK/dV.
 // Phase A: each wave takes query blocks and produces dQ with K and V resident in LDS; phase B: each wave takes key blocks and
@@ -771,14 +587,6 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
     if (s3 && dh == 64 && nb > 8 && nb <= 13) return launch_s3_fwd<13>(qkv, out, lse, B, N, H, scale, s) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;
     if (dh == 64) AS_PICK(launch_fwd, bf16, 64, qkv, out, lse, B, N, H, scale, s);
     AS_PICK(launch_fwd, bf16, 32, qkv, out, lse, B, N, H, scale, s);
-}
-
-int ucfvit_attention_short_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B, int64_t N,
-                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s) {
-    if (dtype != UCFVIT_BF16 || N > 256 || (dh != 32 && dh != 64) || B * H >= (1ll << 31)) return 0;
-    const int nb = (int)((N + 15) / 16);
-    if (dh == 64) AS_PICK(launch_bwd, bf16, 64, qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
-    AS_PICK(launch_bwd, bf16, 32, qkv, dout, lse, delta, dqkv, B, N, H, scale, s);
 }
 
 // fused backward (bf16, head dim 64, N <= 208; needs no delta): 1 = handled, 0 = not applicable, <0 = error
