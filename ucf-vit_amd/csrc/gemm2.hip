@@ -129,7 +129,6 @@ struct Epi2 {
     float alpha;
     float* slab;       // split-K: fp32 partial matrices [splits][M][N] (ld = N); NULL when gridDim.y == 1
     unsigned long long* dbg;  // diagnostic stamps (UCFVIT_GEMM_DBG builds of the bench only); NULL in production
-    int warm;          // 1: touch the C-shaped epilogue input during the K loop (UCFVIT_GEMM_WARM=0 disables, experiments)
     float* cs_partial; // column sums of the output per 128-row block: [2 * tiles_m][N] (CS instantiations only), or NULL
 };
 
@@ -488,7 +487,8 @@ struct Groups3 {
 // generic epilogue decides everything at run time; under the accumulators' register pressure that code spills, and hipcc, which
 // cannot see the asm waits that retire the LDS-DMA, drains vmcnt(0) — loads AND the strips' stores, which share the counter — at
 // every use of a loaded value (124 drains per tile).  A specialised epilogue is straight-line: its one C-shaped input is fetched
-// PD strips ahead with counted waits, its stores are never waited for.
+// PD strips ahead with counted waits, its stores are never waited for.  (A cache-warming DMA touch of that input during the K loop
+// was worth 5 % before this and nothing after it; removed.)
 enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RESIDUAL = 2, EPI_GELU = 3, EPI_GELU_GRAD = 4, EPI_GELU_SAVE_DERIV = 5, EPI_MUL_AUX = 6 };
 
 template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false>
@@ -627,13 +627,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
 #define PP_ISSUE_B(kt_) PP_ISSUE_ONE(LB, BN, Bb, ldb, offB, nBb, nldb, nn0, nN, A_BYTES, kt_)
 #define PP_ISSUE_A(kt_) PP_ISSUE_ONE(LA, BM, Ab, lda, offA, nAb, nlda, nm0, nM, 0, kt_)
 
-        const bf16* warm_base = nullptr;
-        int64_t warm_ld = 0;
-        if (sizeof(OutT) == 2 && !slab && ep.warm) {
-            if (ep.act == UCFVIT_ACT_GELU_GRAD || ep.act == UCFVIT_ACT_MUL_AUX) warm_base = ep.aux_in, warm_ld = ep.ldaux;
-            else if (ep.residual) warm_base = ep.residual, warm_ld = ep.ldr;
-        }
-        const int warm_k0 = nk > 16 ? nk - 16 : 0;          // the last 16 K-tiles each carry 1/16 of the touch
         // One program for both groups; G1 runs it one barrier interval behind G0 (extra barrier before / after the loop).
         if (grp == 1) PP_BARRIER();
 #pragma clang loop unroll(disable)
@@ -643,17 +636,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
             int ksA = ksA0, ksB = ksB0;
             if constexpr (LA == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksA));   // opaque per iteration: the per-fragment XORs are
             if constexpr (LB == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksB));   // recomputed, not hoisted into 12 live VGPRs
-            if (warm_base && kt >= warm_k0) {
-                // pull 1/16 of the tile's C-shaped epilogue input (gelu' pre-activation / residual) into L2 / the memory-side cache
-                // while the MFMAs run, so the epilogue's loads do not pay HBM latency with only a few KB in flight: one 1-KiB DMA
-                // piece per wave per K-tile into a dump area (no result VGPRs; issued before the B pieces, so it is older than
-                // everything the counted waits below leave in flight)
-                const int row = (wave * 16 + (kt - warm_k0)) * 2 + (lane >> 5);
-                int m = m0 + row, n = n0 + (lane & 31) * 8;
-                m = m < M ? m : M - 1;
-                n = n < N ? n : N - 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)(warm_base + (int64_t)m * warm_ld + n), (lptr_t)(smem + 2 * BUF + wave * 1024), 16, 0, 0);
-            }
             PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) + fragment reads
             PP_READ(bufA, bufB, 0);
             PP_BARRIER();
@@ -1069,7 +1051,7 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
 
 template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false>
 int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
-    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 8192;   // pipeline buffers + the cache-warming dump area
+    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128;
     auto kern = gemm3_kernel<LA, LB, OutT, EPI, CS>;
     static bool done = false;
     if (!done) {
@@ -1239,14 +1221,6 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
             return UCFVIT_ERR_UNSUPPORTED;
         }
         ep.cs_partial = d->c_colsum_partial;
-    }
-    {
-        static int warm = -1;
-        if (warm < 0) {
-            const char* e = getenv("UCFVIT_GEMM_WARM");
-            warm = (e && e[0] == '0') ? 0 : 1;
-        }
-        ep.warm = warm;
     }
     {
         const char* e = getenv("UCFVIT_GEMM_DBG");
