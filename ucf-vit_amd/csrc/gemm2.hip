@@ -636,13 +636,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, 
             int ksA = ksA0, ksB = ksB0;
             if constexpr (LA == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksA));   // opaque per iteration: the per-fragment XORs are
             if constexpr (LB == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksB));   // recomputed, not hoisted into 12 live VGPRs
-            PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) + fragment reads
+            PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) ...
+            PP_ISSUE_A(kt);                 // ... and of its OWN rows of the next A tile (that region was last read in MEM(c1) of the tile before)
             PP_READ(bufA, bufB, 0);
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c0)
             PP_BARRIER();
-            PP_ISSUE_A(kt);                 // MEM(c1): DMA of this group's OWN rows of the next A tile (first read by itself, 2 intervals on)
-            PP_READ(bufA, bufB, 1);
+            PP_READ(bufA, bufB, 1);         // MEM(c1): fragment reads only
             if (grp == 1) PP_WAIT_B();      // G1's B half (issued 2 intervals ago) must be visible before G0's next MEM(c0); its A pieces stay in flight
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c1)
