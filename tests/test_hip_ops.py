@@ -367,3 +367,32 @@ def test_dgrad_output_column_sums_byproduct(M, Nout, Kc):
     assert rel_err(cs, ref.sum(0)) < 2e-3
     ops.linear_dgrad_t(dy.to(DEV), wT.to(DEV), act_grad_aux=aux.to(DEV), aux_is_deriv=True, c_colsum=cs, c_colsum_accumulate=True)
     assert rel_err(cs, 2 * ref.sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_row_padded_operands(dtype):
+    """leading dimensions larger than the row length on every matrix of a GEMM (ops.alloc_rows pads activation matrices whose row
+    stride would be a multiple of 8 KiB): forward with bias + residual, data gradient with the saved-derivative multiply, weight
+    gradient; the 256x256, 128x128 and v1 kernels all take lda / ldb / ldc / ldr / ldaux"""
+    from UCF_VIT._hip import ops
+    from UCF_VIT._hip.lib import ACT_MUL_AUX
+    gen = torch.Generator().manual_seed(9)
+    for M, K, N in [(50432, 256, 512), (1000, 384, 256), (300, 96, 72)]:
+        def padded(r, c, scale=1.0):
+            buf = (torch.randn(r, c + 64, generator=gen) * scale).to(dtype).to(DEV)
+            return buf[:, :c]
+        x, res, aux, dy = padded(M, K), padded(M, N), padded(M, K), padded(M, N)
+        w = (torch.randn(N, K, generator=gen) * 0.1).to(dtype).to(DEV)
+        b = torch.randn(N, generator=gen).to(dtype).to(DEV)
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        out = ops.alloc_rows(M, N, dtype, DEV) if N % 4096 == 0 else padded(M, N)
+        ops.linear_fwd(x, w, b, residual=res, out=out)
+        ref = x.double() @ w.double().T + b.double() + res.double()
+        assert rel_err(out.float(), ref) < tol
+        dx = padded(M, K)
+        ops.linear_dgrad(dy, w, act_grad_aux=aux, aux_is_deriv=True, out=dx)
+        assert rel_err(dx.float(), (dy.double() @ w.double()) * aux.double()) < tol
+        dw = ops.linear_wgrad(dy, x)
+        assert rel_err(dw, dy.double().T @ x.double()) < (1e-5 if dtype == torch.float32 else 1e-4)
+    a = ops.alloc_rows(16, 4096, torch.bfloat16, DEV)
+    assert a.stride(0) == 4160 and a.shape == (16, 4096) and ops.alloc_rows(16, 1024, torch.bfloat16, DEV).stride(0) == 1024

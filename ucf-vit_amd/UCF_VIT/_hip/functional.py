@@ -197,14 +197,15 @@ def _bgrad_from(bias, cs):
     return None if acc else out
 
 
-def _dgrad(dy2, p_w, w, aux=None, aux_is_deriv=False, c_colsum=None, c_colsum_accumulate=False):
+def _dgrad(dy2, p_w, w, aux=None, aux_is_deriv=False, c_colsum=None, c_colsum_accumulate=False, out=None):
     """dx = dy·W (optionally x gelu'(aux), or x aux when aux already is the derivative); uses the transposed weight shadow
     when the flat store keeps one.  c_colsum: fp32 [K] that receives the column sums of dx (bias gradient of the layer before)."""
     wT = compute_param_t(p_w, dy2.dtype)
     if wT is not None:
         return ops.linear_dgrad_t(dy2, wT, act_grad_aux=aux, aux_is_deriv=aux_is_deriv, c_colsum=c_colsum,
-                                  c_colsum_accumulate=c_colsum_accumulate)
-    return ops.linear_dgrad(dy2, w, act_grad_aux=aux, aux_is_deriv=aux_is_deriv, c_colsum=c_colsum, c_colsum_accumulate=c_colsum_accumulate)
+                                  c_colsum_accumulate=c_colsum_accumulate, out=out)
+    return ops.linear_dgrad(dy2, w, act_grad_aux=aux, aux_is_deriv=aux_is_deriv, c_colsum=c_colsum, c_colsum_accumulate=c_colsum_accumulate,
+                            out=out)
 
 
 _BIAS_FROM_EPILOGUE = os.environ.get("UCFVIT_BIAS_FROM_EPILOGUE", "1") != "0"   # A/B switch
@@ -286,7 +287,8 @@ def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_p
 def _mlp_fwd(x2, w1, b1, w2, b2, residual, tp=None):
     h = torch.empty((x2.shape[0], w1.shape[0]), dtype=x2.dtype, device=x2.device)
     act = ACT_GELU_SAVE_DERIV if _saves_gelu_deriv(x2.dtype) else ACT_GELU
-    a = ops.linear_fwd(x2, w1, b1, act=act, aux_out=h)                 # K7: fc1 GEMM + bias + erf-GELU (h: pre-activation, or gelu' of it)
+    a = ops.alloc_rows(x2.shape[0], w1.shape[0], x2.dtype, x2.device)  # the next GEMM's K operand: padded rows if the stride is 8 KiB
+    ops.linear_fwd(x2, w1, b1, act=act, aux_out=h, out=a)              # K7: fc1 GEMM + bias + erf-GELU (h: pre-activation, or gelu' of it)
     if tp and tp.rank != 0:
         residual = None
     y = ops.linear_fwd(a, w2, b2, residual=residual)                   # K7: fc2 GEMM + bias (+ residual)
@@ -309,10 +311,12 @@ def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=
         bout, bacc = grad_target(p_b1)
         if bout is None:
             bout = torch.empty(p_b1.shape, dtype=torch.float32, device=dy2.device)
-        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype), c_colsum=bout, c_colsum_accumulate=bacc)
+        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype), c_colsum=bout, c_colsum_accumulate=bacc,
+                    out=ops.alloc_rows(dy2.shape[0], h.shape[1], dy2.dtype, dy2.device))
         g_b1 = None if bacc else bout
     else:
-        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype))
+        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype),
+                    out=ops.alloc_rows(dy2.shape[0], h.shape[1], dy2.dtype, dy2.device))
         g_b1 = _bgrad(p_b1, dh) if need_b1 else None
     g_w1 = _wgrad(p_w1, dh, x2, wq) if needs[0] else None
     dx = _dgrad(dh, p_w1, w1)

@@ -24,17 +24,30 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _chk(t, name):
+def _chk(t, name, rows_ok=False):
+    """rows_ok: a 2-D matrix whose rows are contiguous but padded (stride(0) >= shape[1]) is accepted: the C ABI takes leading dimensions"""
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda) device, got {t.device}. "
                            "UCF_VIT operators run only through libucfvit_hip.so; there is no CPU path.")
     if not t.is_contiguous():
-        raise RuntimeError(f"{name}: tensor must be contiguous")
+        if not (rows_ok and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+            raise RuntimeError(f"{name}: tensor must be contiguous")
     return t
 
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+def alloc_rows(M, N, dtype, device):
+    """[M, N] activation matrix for GEMM operands.  A row stride that is a multiple of 8 KiB makes the rows of a 256-row K-tile land
+    on few memory channels: the fc2 forward / fc1 data-gradient GEMMs of ViT-L (K = 4096 bf16 = 8192-byte rows) measured 262 us at
+    lda = 4096 and 219 us at lda = 4160 (tools/stride_bench.py; other strides make no difference).  Such matrices get 64 elements of
+    row padding; the C ABI takes leading dimensions, so the view is used as is."""
+    es = torch.empty((), dtype=dtype).element_size()
+    if (N * es) % 8192 == 0:
+        return torch.empty((M, N + 64), dtype=dtype, device=device)[:, :N]
+    return torch.empty((M, N), dtype=dtype, device=device)
 
 
 _workspaces = {}
@@ -57,7 +70,7 @@ def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None,
     c_colsum: optional fp32 [N] tensor that receives (+)= the column sums of C — as a by-product of the epilogue where the library
     has one (desc.c_colsum_partial + ucfvit_reduce_rows), else by a separate ucfvit_colsum pass over C."""
     L = _l.load()
-    _chk(A, "gemm.A"), _chk(B, "gemm.B")
+    _chk(A, "gemm.A", rows_ok=True), _chk(B, "gemm.B", rows_ok=True)
     if A.dtype != B.dtype:
         raise TypeError("gemm: A and B must have the same dtype")
     if out is None:
@@ -106,7 +119,7 @@ def wgrad_grouped(items):
     outs = []
     arr = (_l.GemmDesc * n)()
     for i, (dy2, x2, out, acc) in enumerate(items):
-        _chk(dy2, "wgrad.dy"), _chk(x2, "wgrad.x")
+        _chk(dy2, "wgrad.dy", rows_ok=True), _chk(x2, "wgrad.x", rows_ok=True)
         Mtok, N = dy2.shape
         K = x2.shape[1]
         if out is None:
@@ -165,7 +178,7 @@ def reduce_rows(partial, out, accumulate=False):
 
 def colsum(x2, out=None, accumulate=False):
     L = _l.load()
-    _chk(x2, "colsum.x")
+    _chk(x2, "colsum.x", rows_ok=True)
     M, N = x2.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x2.device)
