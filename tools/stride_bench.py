@@ -69,3 +69,11 @@ for pad in (0, 64):
     aa = buf[:, :4096]
     t = timeit(lambda: ops.gemm(dy, aa, 1024, 4096, M, LAYOUT_KS, LAYOUT_KS, out=dw, out_dtype=torch.float32))
     print(f"ld(a) = {4096 + pad:5d}: {t:7.1f} us {2.0 * M * 1024 * 4096 / t / 1e6:7.1f} TF", flush=True)
+print("--- weight operand B [1024, 4096] (fc2 forward), A padded to 4160, ldb varied")
+bufa = torch.randn(M, 4096 + 64, device=dev).bfloat16()
+xa = bufa[:, :4096]
+for pad in (0, 8, 64, 128):
+    wb = (torch.randn(1024, 4096 + pad, device=dev) * 0.05).bfloat16()
+    ww = wb[:, :4096]
+    t = timeit(lambda: ops.gemm(xa, ww, M, 1024, 4096, LAYOUT_KC, LAYOUT_KC, out=out))
+    print(f"ldb = {4096 + pad:5d}: {t:7.1f} us {2.0 * M * 1024 * 4096 / t / 1e6:7.1f} TF", flush=True)

@@ -287,8 +287,7 @@ def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_p
 def _mlp_fwd(x2, w1, b1, w2, b2, residual, tp=None):
     h = torch.empty((x2.shape[0], w1.shape[0]), dtype=x2.dtype, device=x2.device)
     act = ACT_GELU_SAVE_DERIV if _saves_gelu_deriv(x2.dtype) else ACT_GELU
-    a = ops.alloc_rows(x2.shape[0], w1.shape[0], x2.dtype, x2.device)  # the next GEMM's K operand: padded rows if the stride is 8 KiB
-    ops.linear_fwd(x2, w1, b1, act=act, aux_out=h, out=a)              # K7: fc1 GEMM + bias + erf-GELU (h: pre-activation, or gelu' of it)
+    a = ops.linear_fwd(x2, w1, b1, act=act, aux_out=h)                 # K7: fc1 GEMM + bias + erf-GELU (h: pre-activation, or gelu' of it)
     if tp and tp.rank != 0:
         residual = None
     y = ops.linear_fwd(a, w2, b2, residual=residual)                   # K7: fc2 GEMM + bias (+ residual)
@@ -311,12 +310,10 @@ def _mlp_bwd(dy2, x2, saved, w1, w2, p_w1, p_b1, p_w2, p_b2, needs, tp=None, wq=
         bout, bacc = grad_target(p_b1)
         if bout is None:
             bout = torch.empty(p_b1.shape, dtype=torch.float32, device=dy2.device)
-        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype), c_colsum=bout, c_colsum_accumulate=bacc,
-                    out=ops.alloc_rows(dy2.shape[0], h.shape[1], dy2.dtype, dy2.device))
+        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype), c_colsum=bout, c_colsum_accumulate=bacc)
         g_b1 = None if bacc else bout
     else:
-        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype),
-                    out=ops.alloc_rows(dy2.shape[0], h.shape[1], dy2.dtype, dy2.device))
+        dh = _dgrad(dy2, p_w2, w2, aux=h, aux_is_deriv=_saves_gelu_deriv(h.dtype))
         g_b1 = _bgrad(p_b1, dh) if need_b1 else None
     g_w1 = _wgrad(p_w1, dh, x2, wq) if needs[0] else None
     dx = _dgrad(dh, p_w1, w1)

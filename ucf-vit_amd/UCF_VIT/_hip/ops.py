@@ -2,6 +2,7 @@
 current stream and returns torch tensors that own the outputs.  PyTorch is used for device memory and streams only.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -37,17 +38,6 @@ def _chk(t, name, rows_ok=False):
 
 def _p(t):
     return None if t is None else t.data_ptr()
-
-
-def alloc_rows(M, N, dtype, device):
-    """[M, N] activation matrix for GEMM operands.  A row stride that is a multiple of 8 KiB makes the rows of a 256-row K-tile land
-    on few memory channels: the fc2 forward / fc1 data-gradient GEMMs of ViT-L (K = 4096 bf16 = 8192-byte rows) measured 262 us at
-    lda = 4096 and 219 us at lda = 4160 (tools/stride_bench.py; other strides make no difference).  Such matrices get 64 elements of
-    row padding; the C ABI takes leading dimensions, so the view is used as is."""
-    es = torch.empty((), dtype=dtype).element_size()
-    if (N * es) % 8192 == 0:
-        return torch.empty((M, N + 64), dtype=dtype, device=device)[:, :N]
-    return torch.empty((M, N), dtype=dtype, device=device)
 
 
 _workspaces = {}
