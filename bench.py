@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 WORKLOADS = {
     # name: (img, patch, dim, depth, heads, classes, default per-GPU batch)
     "vit_l16_224": dict(img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166),   # 166*197 = 32702 rows -> 128 M-tiles of 256: every GEMM fills whole rounds of 256 CUs
-    "vit_b16_224": dict(img=224, patch=16, dim=768, depth=12, heads=12, classes=1000, batch=256),
+    "vit_b16_224": dict(img=224, patch=16, dim=768, depth=12, heads=12, classes=1000, batch=332),   # 65404 rows -> 256 M-tiles: 3 N-tiles of 256 fill whole rounds
     "vit_tiny16_256": dict(img=256, patch=16, dim=192, depth=12, heads=3, classes=2, batch=256),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
