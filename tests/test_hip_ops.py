@@ -393,3 +393,28 @@ def test_gemm_row_padded_operands(dtype):
         assert rel_err(dx.float(), (dy.double() @ w.double()) * aux.double()) < tol
         dw = ops.linear_wgrad(dy, x)
         assert rel_err(dw, dy.double().T @ x.double()) < (1e-5 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("N,dh", [(197, 64), (196, 32), (120, 64), (100, 32), (50, 64), (17, 32), (208, 32), (230, 64), (230, 32)])
+def test_attention_kernels_all_short_sequence_paths(N, dh):
+    """bf16 attention forward + backward against fp32 softmax(QK^T/sqrt(dh))V on the SAME bf16 inputs, over every dispatch of the
+    short-sequence kernels: fused resident forward (N <= 208) / resident forward (N <= 256) and the fused backward for 4 / 8 / 13
+    blocks of 16 tokens, head dims 64 and 32; N = 230 takes the streaming backward.  Tolerance 2e-2 of the largest reference
+    magnitude (bf16 probabilities and outputs)."""
+    from UCF_VIT._hip import ops
+    B, H = 3, 2
+    gen = torch.Generator().manual_seed(N * 100 + dh)
+    qkv = torch.randn(B * N, 3 * H * dh, generator=gen).bfloat16().to(DEV)
+    do = torch.randn(B * N, H * dh, generator=gen).bfloat16().to(DEV)
+    o, lse = ops.attention_fwd(qkv, B, N, H, dh, dh ** -0.5)
+    dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
+    ref_in = qkv.float().view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3, B, H, N, dh]
+    q, k, v = ref_in[0], ref_in[1], ref_in[2]
+    p = torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1)
+    ref_o = (p @ v).transpose(1, 2).reshape(B * N, H * dh)
+    ref_o.backward(do.float())
+    ref_d = ref_in.grad.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * dh)
+    assert rel_err(o.float(), ref_o.detach()) < 2e-2
+    assert rel_err(dqkv.float(), ref_d) < 2e-2
+    ref_lse = torch.logsumexp((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1).detach() * 1.4426950408889634     # kernels keep it in log2
+    assert float((lse - ref_lse).abs().max()) < 2e-2

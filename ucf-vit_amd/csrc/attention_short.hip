@@ -241,16 +241,31 @@ int launch_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int
 // base ^ 32 d + 4096 chunk) and sched_barriers keep hipcc from hoisting all fragment reads of a phase: 218 VGPRs, no spills
 // (the earlier resident dQ / dKdV kernels spilled 124-564 bytes per lane and were slower than the streaming kernels).
 // =====================================================================================================================
-__device__ __forceinline__ bf16x8 af_row(const char* img, int base_c, int blk) {      // rows 16 blk .. 16 blk + 15, k-chunk c
-    return *reinterpret_cast<const bf16x8*>(img + base_c + blk * 2048);
+template <int RB> __device__ __forceinline__ bf16x8 af_row(const char* img, int base_c, int blk) {   // rows 16 blk .. + 15, k-chunk c
+    return *reinterpret_cast<const bf16x8*>(img + base_c + blk * (16 * RB));
 }
-__device__ __forceinline__ bf16x8 af_tr(const char* img, int base_d, int rc) {         // rows 32 rc .. + 31 transposed, head-dim block d
-    const char* a = img + base_d + rc * 4096;
+template <int RB> __device__ __forceinline__ bf16x8 af_tr(const char* img, int base_d, int rc) {     // rows 32 rc .. + 31 transposed, head-dim block d
+    const char* a = img + base_d + rc * (32 * RB);
     short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a));
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a + 2048));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, a + 16 * RB));
     short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, r);
 }
+// per-lane address bases of the row images (head dim 64: 128-byte rows, 8 slots, swizzle row & 7; head dim 32: 64-byte rows, 4 slots,
+// swizzle by row group, see swz_s): the fragment of k-chunk c of row block blk is at rowb[c] + blk * 16 RB, the transposed fragment of
+// head-dim block d of row chunk rc at (trb ^ 32 d) + rc * 32 RB
+template <int DH> struct AfBases {
+    int rowb[DH / 32], trb;
+    __device__ __forceinline__ AfBases(int lane) {
+        constexpr int RB = DH * 2, SPR = RB / 16;
+        const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+        const int sw_row = swz_s<SPR>(li);                 // blocks start at multiples of 16 rows: the swizzle sees li only
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c) rowb[c] = li * RB + (((4 * c + g) ^ sw_row) << 4);
+        const int sw_tr = swz_s<SPR>(4 * g + tq);          // chunks start at multiples of 32 rows
+        trb = (4 * g + tq) * RB + ((((tp >> 1) ^ sw_tr)) << 4) + (tp & 1) * 8;
+    }
+};
 
 // Only TWO images are resident at a time (K, V for phase A, then Q, dO for phase B), so two workgroups of 4 waves fit a CU
 // (58 KiB of LDS each) and one workgroup's loads overlap the other's MFMA/softmax work (all four images in one 8-wave workgroup
@@ -260,34 +275,37 @@ __device__ __forceinline__ bf16x8 af_tr(const char* img, int base_d, int rc) {  
 // taken in phase A as sum_k P dP from values the wave holds anyway, so no delta kernel and no read of O.
 constexpr int AG_THREADS = 256, AG_WAVES = 4;
 
-template <int ROWS> struct AgStage {
-    static constexpr int NIT = (ROWS * 8 + AG_THREADS - 1) / AG_THREADS;
+template <int ROWS, int DH> struct AgStage {
+    static constexpr int SPR = DH / 8;       // 16-byte slots per row
+    static constexpr int NIT = (ROWS * SPR + AG_THREADS - 1) / AG_THREADS;
     u32x4 v[NIT];
 };
-template <int ROWS>
-__device__ __forceinline__ void ag_fetch(AgStage<ROWS>& st, const bf16* __restrict__ base, int64_t row_stride, int R, int tid) {
+template <int ROWS, int DH>
+__device__ __forceinline__ void ag_fetch(AgStage<ROWS, DH>& st, const bf16* __restrict__ base, int64_t row_stride, int R, int tid) {
+    constexpr int SPR = DH / 8;
 #pragma unroll
-    for (int i = 0; i < AgStage<ROWS>::NIT; ++i) {
+    for (int i = 0; i < AgStage<ROWS, DH>::NIT; ++i) {
         const int p = tid + i * AG_THREADS;
-        const int row = p >> 3, slot = p & 7;
+        const int row = p / SPR, slot = p % SPR;
         st.v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (p < ROWS * 8 && row < R) st.v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + slot * 8);
+        if (p < ROWS * SPR && row < R) st.v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + slot * 8);
     }
 }
-template <int ROWS> __device__ __forceinline__ void ag_store(const AgStage<ROWS>& st, char* lds, int tid) {
+template <int ROWS, int DH> __device__ __forceinline__ void ag_store(const AgStage<ROWS, DH>& st, char* lds, int tid) {
+    constexpr int SPR = DH / 8;
 #pragma unroll
-    for (int i = 0; i < AgStage<ROWS>::NIT; ++i) {
+    for (int i = 0; i < AgStage<ROWS, DH>::NIT; ++i) {
         const int p = tid + i * AG_THREADS;
-        if (p < ROWS * 8) *reinterpret_cast<u32x4*>(lds + img_off<bf16, 64>(p >> 3, p & 7)) = st.v[i];
+        if (p < ROWS * SPR) *reinterpret_cast<u32x4*>(lds + img_off<bf16, DH>(p / SPR, p % SPR)) = st.v[i];
     }
 }
 
-template <int NB, bool EXACT>
+template <int DH, int NB, bool EXACT>
 __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                  const float* __restrict__ lse, bf16* __restrict__ dqkv, int N, int H,
                                                                  float scale, float scale_log2e) {
     typedef bf16 T;
-    constexpr int DH = 64, NDB = 4, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * 128;
+    constexpr int RB = DH * 2, NCH = DH / 32, NDB = DH / 16, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * RB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* slot0 = smem;                 // K, then Q
     char* slot1 = smem + IMG;           // V, then dO
@@ -303,32 +321,35 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
     const T* dobase = dout + b * N * (int64_t)D + h * DH;
     const float* lse_bh = lse + (b * H + h) * N;
     {
-        AgStage<ROWS> sk, sv;
-        ag_fetch<ROWS>(sk, qbase + D, rs, N, tid);
-        ag_fetch<ROWS>(sv, qbase + 2 * D, rs, N, tid);
-        ag_store<ROWS>(sk, slot0, tid);
-        ag_store<ROWS>(sv, slot1, tid);
+        AgStage<ROWS, DH> sk, sv;
+        ag_fetch<ROWS, DH>(sk, qbase + D, rs, N, tid);
+        ag_fetch<ROWS, DH>(sv, qbase + 2 * D, rs, N, tid);
+        ag_store<ROWS, DH>(sk, slot0, tid);
+        ag_store<ROWS, DH>(sv, slot1, tid);
     }
     for (int i = tid; i < ROWS; i += AG_THREADS) {
         ldsLse[i] = i < N ? lse_bh[i] : INFINITY;    // +inf -> P = 0 for padding queries
         ldsDelta[i] = 0.f;                           // phase A fills the blocks that exist
     }
-    AgStage<ROWS> sq, sdo;                           // phase B's images travel while phase A computes
-    ag_fetch<ROWS>(sq, qbase, rs, N, tid);
-    ag_fetch<ROWS>(sdo, dobase, D, N, tid);
+    AgStage<ROWS, DH> sq, sdo;                           // phase B's images travel while phase A computes
+    ag_fetch<ROWS, DH>(sq, qbase, rs, N, tid);
+    ag_fetch<ROWS, DH>(sdo, dobase, D, N, tid);
     __syncthreads();
 
-    const int rowb0 = li * 128 + ((g ^ (li & 7)) << 4), rowb1 = rowb0 ^ 64;
-    const int tq = li >> 2, tp = li & 3;
-    const int trb = (4 * g + tq) * 128 + ((((tp >> 1) ^ (4 * (g & 1) + tq))) << 4) + (tp & 1) * 8;
+    const AfBases<DH> ab(lane);
+    const int trb = ab.trb;
     constexpr int nb_ = NB;
     const int nqb = (N + 15) / 16;
 
     // ---------------- phase A: dQ (K in slot 0, V in slot 1) -----------------------------------------------------------
     for (int qb = wave; qb < nqb; qb += AG_WAVES) {
         const int q = qb * 16 + li;
-        const bf16x8 qf0 = s_frag_global<T, DH>(qbase, rs, q, N, 0, lane), qf1 = s_frag_global<T, DH>(qbase, rs, q, N, 1, lane);
-        const bf16x8 do0 = s_frag_global<T, DH>(dobase, D, q, N, 0, lane), do1 = s_frag_global<T, DH>(dobase, D, q, N, 1, lane);
+        bf16x8 qf[NCH], dof[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
+            dof[c] = s_frag_global<T, DH>(dobase, D, q, N, c, lane);
+        }
         const float my_lse = ldsLse[q];
         // delta[q] = sum_d dO[q][d] O[q][d] = sum_k P[q][k] dP[q][k]: taken here from the P and dP this wave holds anyway (one row of
         // queries per lane column), so the separate delta kernel and its read of O and dO are not needed
@@ -337,10 +358,11 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            MmaS<T>::mma(sacc, af_row(slot0, rowb0, kb), qf0);
-            MmaS<T>::mma(sacc, af_row(slot0, rowb1, kb), qf1);
-            MmaS<T>::mma(dp, af_row(slot1, rowb0, kb), do0);
-            MmaS<T>::mma(dp, af_row(slot1, rowb1, kb), do1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                MmaS<T>::mma(sacc, af_row<RB>(slot0, ab.rowb[c], kb), qf[c]);
+                MmaS<T>::mma(dp, af_row<RB>(slot1, ab.rowb[c], kb), dof[c]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -my_lse));
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
         for (int rc = 0; rc < NRC; ++rc) {
             const bf16x8 f = s_frag_acc<T, nb_>(ds, rc);
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(dq[d], af_tr(slot0, trb ^ (d << 5), rc), f);
+            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(dq[d], af_tr<RB>(slot0, trb ^ (d << 5), rc), f);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < N) {
@@ -379,23 +401,28 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
         }
     }
     __syncthreads();                     // every wave is done with K and V
-    ag_store<ROWS>(sq, slot0, tid);
-    ag_store<ROWS>(sdo, slot1, tid);
+    ag_store<ROWS, DH>(sq, slot0, tid);
+    ag_store<ROWS, DH>(sdo, slot1, tid);
     __syncthreads();
 
     // ---------------- phase B: dK, dV (Q in slot 0, dO in slot 1), reverse wave order -----------------------------------
     for (int kb = AG_WAVES - 1 - wave; kb < nqb; kb += AG_WAVES) {
         const int key = kb * 16 + li;
-        const bf16x8 kf0 = s_frag_global<T, DH>(qbase + D, rs, key, N, 0, lane), kf1 = s_frag_global<T, DH>(qbase + D, rs, key, N, 1, lane);
-        const bf16x8 vf0 = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, 0, lane), vf1 = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, 1, lane);
+        bf16x8 kf[NCH], vf[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            kf[c] = s_frag_global<T, DH>(qbase + D, rs, key, N, c, lane);
+            vf[c] = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, c, lane);
+        }
         f32x4 pm[NB], ds[NB];
 #pragma unroll
         for (int qb = 0; qb < NB; ++qb) {
             f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            MmaS<T>::mma(sacc, af_row(slot0, rowb0, qb), kf0);
-            MmaS<T>::mma(sacc, af_row(slot0, rowb1, qb), kf1);
-            MmaS<T>::mma(dp, af_row(slot1, rowb0, qb), vf0);
-            MmaS<T>::mma(dp, af_row(slot1, rowb1, qb), vf1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                MmaS<T>::mma(sacc, af_row<RB>(slot0, ab.rowb[c], qb), kf[c]);
+                MmaS<T>::mma(dp, af_row<RB>(slot1, ab.rowb[c], qb), vf[c]);
+            }
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsLse + qb * 16 + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
 #pragma unroll
@@ -418,8 +445,8 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
             const bf16x8 fs = s_frag_acc<T, nb_>(ds, rc);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
-                MmaS<T>::mma(dv[d], af_tr(slot1, trb ^ (d << 5), rc), fp);
-                MmaS<T>::mma(dk[d], af_tr(slot0, trb ^ (d << 5), rc), fs);
+                MmaS<T>::mma(dv[d], af_tr<RB>(slot1, trb ^ (d << 5), rc), fp);
+                MmaS<T>::mma(dk[d], af_tr<RB>(slot0, trb ^ (d << 5), rc), fs);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -449,11 +476,11 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
 // (ii) the six-base addressing and sched_barriers of the fused backward, which bring it under the 170 VGPRs three waves per SIMD
 // allow.  One more workgroup per CU = one more head's loads in flight behind the MFMA / softmax work of the other two.
 // =====================================================================================================================
-template <int NB, bool EXACT>
+template <int DH, int NB, bool EXACT>
 __global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
                                                                      int N, int H, float scale_log2e) {
     typedef bf16 T;
-    constexpr int DH = 64, NDB = 4, NRC = (NB + 1) / 2, ROWS = NB * 16, IMG = ROWS * 128;
+    constexpr int RB = DH * 2, NCH = DH / 32, NDB = DH / 16, NRC = (NB + 1) / 2, ROWS = NB * 16, IMG = ROWS * RB;
     static_assert(NRC * 32 - ROWS <= 16, "the last transposed chunk may only run into K's first 16 rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsV = smem;
@@ -466,28 +493,29 @@ __global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* 
     const int64_t rs = 3 * (int64_t)D;
     const T* qbase = qkv + b * N * rs + h * DH;
     {
-        AgStage<ROWS> sk, sv;
-        ag_fetch<ROWS>(sk, qbase + D, rs, N, tid);
-        ag_fetch<ROWS>(sv, qbase + 2 * D, rs, N, tid);
-        ag_store<ROWS>(sk, ldsK, tid);
-        ag_store<ROWS>(sv, ldsV, tid);
+        AgStage<ROWS, DH> sk, sv;
+        ag_fetch<ROWS, DH>(sk, qbase + D, rs, N, tid);
+        ag_fetch<ROWS, DH>(sv, qbase + 2 * D, rs, N, tid);
+        ag_store<ROWS, DH>(sk, ldsK, tid);
+        ag_store<ROWS, DH>(sv, ldsV, tid);
     }
     __syncthreads();
-    const int rowb0 = li * 128 + ((g ^ (li & 7)) << 4), rowb1 = rowb0 ^ 64;
-    const int tq = li >> 2, tp = li & 3;
-    const int trb = (4 * g + tq) * 128 + ((((tp >> 1) ^ (4 * (g & 1) + tq))) << 4) + (tp & 1) * 8;
+    const AfBases<DH> ab(lane);
+    const int trb = ab.trb;
     constexpr int nb_ = NB;
     const int nqb = (N + 15) / 16;
     for (int qb = wave; qb < nqb; qb += AG_WAVES) {
         const int q = qb * 16 + li;
-        const bf16x8 qf0 = s_frag_global<T, DH>(qbase, rs, q, N, 0, lane), qf1 = s_frag_global<T, DH>(qbase, rs, q, N, 1, lane);
+        bf16x8 qf[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
         f32x4 s[NB];
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            MmaS<T>::mma(s[kb], af_row(ldsK, rowb0, kb), qf0);
-            MmaS<T>::mma(s[kb], af_row(ldsK, rowb1, kb), qf1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) MmaS<T>::mma(s[kb], af_row<RB>(ldsK, ab.rowb[c], kb), qf[c]);
             if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) {   // only the ragged / padding key blocks pay for masking
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[kb][r] = (kb * 16 + 4 * g + r < N) ? s[kb][r] : -INFINITY;
@@ -514,7 +542,7 @@ __global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* 
         for (int rc = 0; rc < NRC; ++rc) {
             const bf16x8 pf = s_frag_acc<T, nb_>(s, rc);
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(o[d], af_tr(ldsV, trb ^ (d << 5), rc), pf);
+            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(o[d], af_tr<RB>(ldsV, trb ^ (d << 5), rc), pf);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < N) {
@@ -532,35 +560,35 @@ __global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* 
     }
 }
 
-template <int NB>
+template <int DH, int NB>
 int launch_s3_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
-    constexpr size_t smem = 2 * (size_t)NB * 16 * 128;
+    constexpr size_t smem = 2 * (size_t)NB * 16 * (DH * 2);
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)(B * H)), block(AG_THREADS);
     if ((N + 15) / 16 == NB) {
-        if (int rc = big_lds(attn_s3_fwd_kernel<NB, true>, smem)) return rc;
-        hipLaunchKernelGGL((attn_s3_fwd_kernel<NB, true>), grid, block, smem, s, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, sl2);
+        if (int rc = big_lds(attn_s3_fwd_kernel<DH, NB, true>, smem)) return rc;
+        hipLaunchKernelGGL((attn_s3_fwd_kernel<DH, NB, true>), grid, block, smem, s, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, sl2);
     } else {
-        if (int rc = big_lds(attn_s3_fwd_kernel<NB, false>, smem)) return rc;
-        hipLaunchKernelGGL((attn_s3_fwd_kernel<NB, false>), grid, block, smem, s, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, sl2);
+        if (int rc = big_lds(attn_s3_fwd_kernel<DH, NB, false>, smem)) return rc;
+        hipLaunchKernelGGL((attn_s3_fwd_kernel<DH, NB, false>), grid, block, smem, s, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, sl2);
     }
     UCF_LAUNCH_CHECK("ucfvit_attention_fwd(short, 3 per CU)");
     return UCFVIT_OK;
 }
 
-template <int NB>
+template <int DH, int NB>
 int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
     constexpr int ROWS = ((NB + 1) / 2) * 32;
-    constexpr size_t smem = 2 * (size_t)ROWS * 128 + 2 * ROWS * sizeof(float);
+    constexpr size_t smem = 2 * (size_t)ROWS * (DH * 2) + 2 * ROWS * sizeof(float);
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)(B * H)), block(AG_THREADS);
     if ((N + 15) / 16 == NB) {
-        if (int rc = big_lds(attn_g_bwd_kernel<NB, true>, smem)) return rc;
-        hipLaunchKernelGGL((attn_g_bwd_kernel<NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+        if (int rc = big_lds(attn_g_bwd_kernel<DH, NB, true>, smem)) return rc;
+        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
                            (int)H, scale, sl2);
     } else {
-        if (int rc = big_lds(attn_g_bwd_kernel<NB, false>, smem)) return rc;
-        hipLaunchKernelGGL((attn_g_bwd_kernel<NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+        if (int rc = big_lds(attn_g_bwd_kernel<DH, NB, false>, smem)) return rc;
+        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
                            (int)H, scale, sl2);
     }
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(fused)");
@@ -584,19 +612,25 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
     if (dtype != UCFVIT_BF16 || N > 256 || (dh != 32 && dh != 64) || B * H >= (1ll << 31)) return 0;
     const int nb = (int)((N + 15) / 16);
     static const bool s3 = [] { const char* e = getenv("UCFVIT_ATTN_FWD_S3"); return !(e && e[0] == '0'); }();
-    if (s3 && dh == 64 && nb > 8 && nb <= 13) return launch_s3_fwd<13>(qkv, out, lse, B, N, H, scale, s) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;
+    if (s3 && nb > 8 && nb <= 13) {
+        const int rc = dh == 64 ? launch_s3_fwd<64, 13>(qkv, out, lse, B, N, H, scale, s) : launch_s3_fwd<32, 13>(qkv, out, lse, B, N, H, scale, s);
+        return rc == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;
+    }
     if (dh == 64) AS_PICK(launch_fwd, bf16, 64, qkv, out, lse, B, N, H, scale, s);
     AS_PICK(launch_fwd, bf16, 32, qkv, out, lse, B, N, H, scale, s);
 }
 
-// fused backward (bf16, head dim 64, N <= 208; needs no delta): 1 = handled, 0 = not applicable, <0 = error
+// fused backward (bf16, head dim 64 or 32, N <= 208; needs no delta): 1 = handled, 0 = not applicable, <0 = error
 int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
                                float scale, int dtype, hipStream_t s) {
-    if (dtype != UCFVIT_BF16 || N > 208 || dh != 64 || B * H >= (1ll << 31)) return 0;   // 14..16 blocks would spill: streaming pair
+    if (dtype != UCFVIT_BF16 || N > 208 || (dh != 64 && dh != 32) || B * H >= (1ll << 31)) return 0;   // 14..16 blocks would spill: streaming pair
     const int nb = (int)((N + 15) / 16);
     int rc;
-    if (nb <= 4) rc = launch_fused_bwd<4>(qkv, dout, lse, dqkv, B, N, H, scale, s);
-    else if (nb <= 8) rc = launch_fused_bwd<8>(qkv, dout, lse, dqkv, B, N, H, scale, s);
-    else rc = launch_fused_bwd<13>(qkv, dout, lse, dqkv, B, N, H, scale, s);
+#define AF_BWD(DH_)                                                                            \
+    (nb <= 4 ? launch_fused_bwd<DH_, 4>(qkv, dout, lse, dqkv, B, N, H, scale, s)               \
+             : nb <= 8 ? launch_fused_bwd<DH_, 8>(qkv, dout, lse, dqkv, B, N, H, scale, s)     \
+                       : launch_fused_bwd<DH_, 13>(qkv, dout, lse, dqkv, B, N, H, scale, s))
+    rc = dh == 64 ? AF_BWD(64) : AF_BWD(32);
+#undef AF_BWD
     return rc == UCFVIT_OK ? 1 : rc;
 }
