@@ -159,6 +159,30 @@ def test_bf16_loss_curve_tracks_cpu_reference():
     assert got[-1] < 0.97 * got[0] and want[-1] < 0.97 * want[0], (got[0], got[-1], want[0], want[-1])
 
 
+def test_deferred_weight_gradients_accumulate_and_serve_autograd_grad():
+    """the grouped weight-gradient launches are deferred to the end of backward (functional.WgradQueue): (i) two backward passes
+    without zero_grad accumulate exactly twice the gradient into the flat buffer, (ii) torch.autograd.grad() sees finished
+    gradients, (iii) a model WITHOUT a flat store (plain parameters) gets the same numbers"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    g = load_golden("model_vit_small.npz")
+    x, y = g["x"].to(DEV), g["labels"].to(DEV)
+    m = build(VIT, VIT_KW, 21)
+    cross_entropy_loss(m(x, VARS), y).backward()
+    once = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, g["g." + k]) < 1e-3, k
+    cross_entropy_loss(m(x, VARS), y).backward()              # accumulate
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, 2 * once[k]) < 1e-5, k
+    m2 = build(VIT, VIT_KW, 21)
+    params = [p for p in m2.parameters()]
+    grads = torch.autograd.grad(cross_entropy_loss(m2(x, VARS), y), params)
+    torch.cuda.synchronize()
+    for (k, _), gr in zip(m2.named_parameters(), grads):
+        assert rel_err(gr, once[k]) < 1e-5, k
+
+
 def test_bf16_shadow_follows_master():
     from UCF_VIT.simple.arch import VIT
     from UCF_VIT.utils.metrics import cross_entropy_loss
