@@ -478,8 +478,10 @@ struct Problem3 {
     int64_t lda, ldb, ldc;
     int M, N, tiles_m, tiles_n, tile_start, accumulate;
 };
-struct Groups3 {
-    Problem3 p[GROUP_MAX];
+// NP = problem slots of the kernel-argument record: a single GEMM carries 1 (a 2.3-KiB argument segment per launch measurably
+// lengthens the gap in front of the kernel), a grouped launch GROUP_MAX
+template <int NP> struct GroupsT {
+    Problem3 p[NP];
     int n, total_tiles;
 };
 
@@ -491,8 +493,10 @@ struct Groups3 {
 // was worth 5 % before this and nothing after it; removed.)
 enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_RESIDUAL = 2, EPI_GELU = 3, EPI_GELU_GRAD = 4, EPI_GELU_SAVE_DERIV = 5, EPI_MUL_AUX = 6 };
 
-template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false>
-__global__ __launch_bounds__(512) void gemm3_kernel(Groups3 gt, int K, Epi2 ep, int k_per_split) {
+typedef GroupsT<GROUP_MAX> Groups3;
+
+template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false, int NP = GROUP_MAX>
+__global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 ep, int k_per_split) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1049,10 +1053,10 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
     return UCFVIT_OK;
 }
 
-template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false>
-int launch3g(const Groups3& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
+template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false, int NP = GROUP_MAX>
+int launch3g(const GroupsT<NP>& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
     constexpr size_t smem = 2 * (size_t)(256 + 256) * 128;
-    auto kern = gemm3_kernel<LA, LB, OutT, EPI, CS>;
+    auto kern = gemm3_kernel<LA, LB, OutT, EPI, CS, NP>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1096,7 +1100,7 @@ inline void fill_problem(Problem3& P, const ucfvit_gemm_desc* d, int tile_start)
 
 template <int LA, int LB, typename OutT>
 int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
-    Groups3 gt;
+    GroupsT<1> gt;
     memset(&gt, 0, sizeof(gt));
     fill_problem(gt.p[0], d, 0);
     gt.n = 1;
@@ -1106,22 +1110,22 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
         if (!generic_epilogue_only() && p.splits == 1 && !ep.slab && !d->accumulate && d->N >= 8) {
             const int K_ = (int)d->K;
             if (ep.act == UCFVIT_ACT_NONE && !ep.residual && !ep.aux_out)
-                return launch3g<LA, LB, OutT, EPI_PLAIN>(gt, K_, ep, 1, p.k_per_split, s);
+                return launch3g<LA, LB, OutT, EPI_PLAIN, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_NONE && ep.residual && !ep.aux_out)
-                return launch3g<LA, LB, OutT, EPI_RESIDUAL>(gt, K_, ep, 1, p.k_per_split, s);
+                return launch3g<LA, LB, OutT, EPI_RESIDUAL, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_GELU && !ep.residual)
-                return launch3g<LA, LB, OutT, EPI_GELU>(gt, K_, ep, 1, p.k_per_split, s);
+                return launch3g<LA, LB, OutT, EPI_GELU, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_GELU_GRAD && !ep.residual && !ep.aux_out)
-                return launch3g<LA, LB, OutT, EPI_GELU_GRAD>(gt, K_, ep, 1, p.k_per_split, s);
+                return launch3g<LA, LB, OutT, EPI_GELU_GRAD, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV && !ep.residual)
-                return launch3g<LA, LB, OutT, EPI_GELU_SAVE_DERIV>(gt, K_, ep, 1, p.k_per_split, s);
+                return launch3g<LA, LB, OutT, EPI_GELU_SAVE_DERIV, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_MUL_AUX && !ep.residual && !ep.aux_out) {
-                if (ep.cs_partial) return launch3g<LA, LB, OutT, EPI_MUL_AUX, true>(gt, K_, ep, 1, p.k_per_split, s);
-                return launch3g<LA, LB, OutT, EPI_MUL_AUX>(gt, K_, ep, 1, p.k_per_split, s);
+                if (ep.cs_partial) return launch3g<LA, LB, OutT, EPI_MUL_AUX, true, 1>(gt, K_, ep, 1, p.k_per_split, s);
+                return launch3g<LA, LB, OutT, EPI_MUL_AUX, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             }
         }
     }
-    return launch3g<LA, LB, OutT>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
+    return launch3g<LA, LB, OutT, EPI_GENERIC, false, 1>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
 }
 
 static bool generic_epilogue_only() {
