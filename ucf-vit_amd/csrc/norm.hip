@@ -252,17 +252,17 @@ inline int colsum_chunks(int64_t M) {
 }
 
 // workgroups of 4 waves (one row per wave at a time).  Forward: 2048 workgroups = 32 waves per CU (bytes in flight = resident
-// waves x one row; +0.9 % on the ViT-L step over 512).  Backward stays at 512: every workgroup adds a row of partial sums to the
-// second stage and more of them measured no faster.
+// waves x one row; +0.9 % on the ViT-L step over 512).  Backward: 768 = the three workgroups per CU its registers allow (61 us at
+// 512, 54 us at 768, 68 us at 832 where a second partial round starts; tools/ln_bench.py).
 inline int ln_grid_cap(bool backward) {
     static int fwd = 0, bwd = 0;
     if (!fwd) {
         const char* e = getenv("UCFVIT_LN_GRID_FWD");
         const char* b = getenv("UCFVIT_LN_GRID_BWD");
         fwd = e ? atoi(e) : 2048;
-        bwd = b ? atoi(b) : 512;
+        bwd = b ? atoi(b) : 768;
         if (fwd < 1) fwd = 2048;
-        if (bwd < 1) bwd = 512;
+        if (bwd < 1) bwd = 768;
     }
     return backward ? bwd : fwd;
 }
