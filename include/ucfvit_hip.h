@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 4
+#define UCFVIT_ABI_VERSION 5
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -163,6 +163,24 @@ int ucfvit_tokens_fwd(const void* patches, const void* cls, const void* pos, voi
 int ucfvit_tokens_bwd(const void* dout, void* dpatches, float* dpos, float* dcls, int64_t B, int64_t L, int64_t D,
                       int has_cls, int accumulate, int dtype, void* stream);
 
+/* Adaptive-patching front end (VIT.forward_features / _pos_embed with adaptive_patching=True, arch.py:465-467, :366-393).
+ * The data loader delivers the token sequence already cut and resized: x fp32 [B][C][S][P] (S tokens of P = p^nd pixels per
+ * channel) and seq_ps fp32 [B][S][kin] (kin = 3 for 2-D, 4 for 3-D input: position and size of each token).
+ * ucfvit_seq_patches: rows_out[b*S+s][p*C+c] = x[b][c][s][p]  (einops 'b c s p -> b s (p c)'), in `dtype`; C*P <= 16384.
+ * ucfvit_adaptive_pos_fwd: out[b][0] = cls (if has_cls; its position embedding is zero, arch.py:381-385),
+ *     out[b][t+pre] = x[b][t] + GELU(seq_ps[b][t] . w^T + bias)     (adaptive_pos_dep_emb = Linear(kin, D) + erf-GELU, arch.py:311-321)
+ *     x [B*S][D], w [D][kin], bias [D], cls [D], out [B][S+pre][D], all `dtype`; the pre-activation is recomputed in backward.
+ * ucfvit_adaptive_pos_bwd: dx [B*S][D] = dout[:,pre:] (or NULL), dw fp32 [D][kin], dbias fp32 [D], dcls fp32 [D] (each may be NULL);
+ *     accumulate is a bit mask (1: dw +=, 2: dbias +=, 4: dcls +=).  workspace: ucfvit_adaptive_pos_bwd_workspace bytes.
+ *     Deterministic: per-chunk partial sums in the workspace, then one ordered pass. */
+int ucfvit_seq_patches(const float* x, void* rows_out, int64_t B, int64_t C, int64_t S, int64_t P, int dtype, void* stream);
+int ucfvit_adaptive_pos_fwd(const void* x, const float* seq_ps, const void* w, const void* bias, const void* cls, void* out,
+                            int64_t B, int64_t S, int64_t D, int kin, int has_cls, int dtype, void* stream);
+int64_t ucfvit_adaptive_pos_bwd_workspace(int64_t B, int64_t S, int64_t D, int kin, int has_cls, int dtype);
+int ucfvit_adaptive_pos_bwd(const void* dout, const float* seq_ps, const void* w, const void* bias, void* dx, float* dw, float* dbias,
+                            float* dcls, int64_t B, int64_t S, int64_t D, int kin, int has_cls, int accumulate, void* workspace,
+                            int dtype, void* stream);
+
 /* Softmax cross-entropy, mean over the batch (nn.CrossEntropyLoss, training_scripts/train_class_simple.py:24-30).
  * logits [B][C] dtype, labels int64 [B]; loss: fp32 scalar (device); row_loss: fp32 [B] per-sample losses (also scratch);
  * dlogits [B][C] dtype = grad_scale*(softmax - onehot)/B, or NULL. */
@@ -197,7 +215,9 @@ int ucfvit_unshuffle_bwd(const void* dout, const int64_t* ids_restore, void* dx,
 /* MAE reconstruction loss against patchify(img) without materialising the target (utils/misc.py:14-33 'nchpwq->nhwpqc',
  * training_scripts/train_masked_simple.py:43-47; masked variant utils/metrics.py:11-17).
  * pred [B][L][p^nd*C] dtype with per-patch order (ph,pw[,pd],c); img NCHW(D) fp32; mask fp32 [B][L] or NULL (plain MSE over all).
- * loss: fp32 scalar (device, overwritten); dpred = grad_scale * dloss/dpred (or NULL). workspace: >= 2049 floats. */
+ * loss: fp32 scalar (device, overwritten); dpred = grad_scale * dloss/dpred (or NULL). workspace: >= 2049 floats.
+ * nd = 1: the adaptive-patching target (train_masked_simple.py:24-32): img is the token sequence x fp32 [B][C][S][P], dims = {S},
+ * p = P pixels per token and channel, pred [B][S][P*C] with per-token order (p, c) = rearrange 'b c s p -> b s (p c)'. */
 int ucfvit_patch_mse(const void* pred, const float* img, const float* mask, float* loss, void* dpred, int64_t B, int64_t C,
                      const int64_t* dims, int nd, int64_t p, float grad_scale, float* workspace, int dtype, void* stream);
 

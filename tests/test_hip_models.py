@@ -48,6 +48,106 @@ def test_vit_small_vs_reference(dtype, tol):
         assert p.grad.data_ptr() == st.flat_g.data_ptr() + 4 * o
 
 
+ADAPTIVE_CASES = [("model_vit_adaptive.npz", dict(img_size=[32, 32], patch_size=8, in_chans=3, twoD=True, use_adaptive_pos_emb=True), 52),
+                  ("model_vit_adaptive_learnpos.npz", dict(img_size=[32, 32], patch_size=8, in_chans=3, twoD=True, use_adaptive_pos_emb=False), 53),
+                  ("model_vit_adaptive_3d.npz", dict(img_size=[16, 16, 16], patch_size=4, in_chans=1, twoD=False, use_adaptive_pos_emb=True), 56)]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("name,kw,seed", ADAPTIVE_CASES)
+def test_vit_adaptive_patching_vs_reference(name, kw, seed, dtype, tol):
+    """VIT(adaptive_patching=True) (arch.py:282-289, :311-321, :366-393, :465-467): x [B, C, S, P] pre-cut patches + seq_ps [B, S, 3|4];
+    fixtures generated from the reference by tests/golden/make_golden_adaptive.py"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    g = load_golden(name)
+    m = VIT(num_classes=5, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True, fixed_length=12, **kw)
+    m.load_state_dict(det_state_dict(m, seed, keep=()))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    out = m(g["x"].to(DEV), VARS, g["seq_ps"].to(DEV))
+    loss = cross_entropy_loss(out, g["labels"].to(DEV))
+    loss.backward()
+    assert out.dtype == dtype
+    assert rel_err(out.float(), g["logits"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    for k, p in m.named_parameters():
+        ref = g["g." + k]
+        if float(ref.abs().max()) == 0.0:                    # pos_embed is unused when positions come from seq_ps
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert p.grad is not None, k
+            assert rel_err(p.grad, ref) < tol, k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("name,adaptive_pos,seed", [("model_mae_adaptive.npz", True, 58), ("model_mae_adaptive_learnpos.npz", False, 59)])
+def test_mae_adaptive_patching_vs_reference(name, adaptive_pos, seed, dtype, tol):
+    """MAE(adaptive_patching=True) (arch.py:538-755, train_masked_simple.py:24-32): the mask is bit-exact, prediction / loss / every
+    gradient within the fp32 (bf16) tolerance; the target 'b c s p -> b s (p c)' is read in place by the loss kernel"""
+    from UCF_VIT.simple.arch import MAE
+    from UCF_VIT.utils.metrics import seq_mse_loss
+    g = load_golden(name)
+    m = MAE(img_size=[32, 32], patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True, fixed_length=12,
+            class_token=False, weight_init='skip', mask_ratio=0.5, linear_decoder=False, decoder_depth=1, decoder_embed_dim=32,
+            decoder_num_heads=1, mlp_ratio_decoder=4.0, use_adaptive_pos_emb=adaptive_pos)
+    m.load_state_dict(det_state_dict(m, seed, keep=()))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    x, sp = g["x"].to(DEV), g["seq_ps"].to(DEV)
+    pred, mask = m(x, VARS, sp, noise=g["noise"].to(DEV))
+    assert torch.equal(mask.cpu(), g["mask"])
+    loss = seq_mse_loss(pred, x)
+    loss.backward()
+    assert rel_err(pred.float(), g["pred"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    with torch.no_grad():
+        lm = seq_mse_loss(pred.detach(), x, mask)
+    assert abs(lm.item() - g["loss_masked"].item()) < tol * max(1.0, abs(g["loss_masked"].item()))
+    for k, p in m.named_parameters():
+        ref = g["g." + k]
+        if float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert p.grad is not None, k
+            assert rel_err(p.grad, ref) < tol, k
+
+
+def test_vit_adaptive_patching_trains_like_the_oracle():
+    """10 AdamW steps on one adaptive batch (bf16 HIP path against the fp32 CPU oracle): same loss curve, loss goes down"""
+    from oracle import ucf_vit_ref as R
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer
+    g = load_golden("model_vit_adaptive.npz")
+    kw = ADAPTIVE_CASES[0][1]
+    m = VIT(num_classes=5, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True, fixed_length=12, **kw)
+    sd = det_state_dict(m, 52, keep=())
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    m.set_compute_dtype(torch.bfloat16)
+    ref = R.AdaptiveVIT(patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=2, num_heads=2, fixed_length=12)
+    ref.load_state_dict(sd)
+    opt = configure_optimizer(m, 2e-3, 0.9, 0.95, 1e-5)
+    ropt = R.configure_optimizer(ref, 2e-3, 0.9, 0.95, 1e-5)
+    x, sp, y = g["x"], g["seq_ps"], g["labels"]
+    got, want = [], []
+    for _ in range(10):
+        loss = cross_entropy_loss(m(x.to(DEV), VARS, sp.to(DEV)), y.to(DEV))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        got.append(loss.item())
+        rl = torch.nn.CrossEntropyLoss()(ref(x, None, sp), y)
+        ropt.zero_grad()
+        rl.backward()
+        ropt.step()
+        want.append(rl.item())
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert abs(a - b) <= 0.05 * abs(b) + 0.02, (i, a, b)
+    assert got[-1] < 0.9 * got[0] and want[-1] < 0.9 * want[0], (got, want)
+
+
 def test_vit_tiny_config_T_vs_reference():
     """BASELINE.json configs[0]: ViT-Tiny/16 on catsdogs-shaped input (256x256, pixels 0..255, 2 classes), fp32"""
     from UCF_VIT.simple.arch import VIT
@@ -346,6 +446,25 @@ def test_train_masked_simple_entry_point_runs(tmp_path):
     cfg["model"]["warmup_steps"] = 2
     cfg["load_balancing"]["batches_per_rank_epoch"]["catsdogs"] = 8
     out = _run_entry("train_masked_simple.py", cfg, tmp_path, 29578)
+    losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and losses[1] < losses[0], out
+
+
+def test_train_scripts_run_the_adaptive_patching_configuration(tmp_path):
+    """the reference's imagenet / basic_ct configs set adaptive_patching: True, fixed_length: 196, use_adaptive_pos_emb: True
+    (configs/imagenet/classification/base_config.yaml:46-49): both entry scripts train on token sequences [B, C, S, P] + seq_ps"""
+    cfg = _smoke_cfg()
+    cfg["trainer"]["data_type"] = "bfloat16"
+    a = cfg["model"]["net"]["init_args"]
+    a.update(tile_size=[64, 64], patch_size=8, embed_dim=128, depth=3, num_heads=2, adaptive_patching=True, fixed_length=49, use_adaptive_pos_emb=True)
+    cfg["model"]["lr"] = 1e-3
+    cfg["model"]["warmup_steps"] = 2
+    cfg["load_balancing"]["batches_per_rank_epoch"]["catsdogs"] = 8
+    out = _run_entry("train_class_simple.py", cfg, tmp_path, 29580)
+    losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses), out
+    a.update(mask_ratio=0.75, linear_decoder=False, decoder_depth=2, decoder_embed_dim=64, decoder_num_heads=2, mlp_ratio_decoder=4.0)
+    out = _run_entry("train_masked_simple.py", cfg, tmp_path, 29581)
     losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
     assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and losses[1] < losses[0], out
 

@@ -418,3 +418,52 @@ def test_attention_kernels_all_short_sequence_paths(N, dh):
     assert rel_err(dqkv.float(), ref_d) < 2e-2
     ref_lse = torch.logsumexp((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1).detach() * 1.4426950408889634     # kernels keep it in log2
     assert float((lse - ref_lse).abs().max()) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------- adaptive-patching front end
+@pytest.mark.parametrize("B,C,S,P", [(2, 3, 12, 64), (3, 1, 50, 256), (1, 4, 7, 27), (2, 3, 196, 256)])
+def test_seq_patches_is_an_exact_rearrangement(B, C, S, P):
+    """einops 'b c s p -> b s (p c)' (arch.py:466): bit-exact in fp32, one rounding in bf16"""
+    from UCF_VIT._hip import ops
+    x = torch.randn(B, C, S, P, generator=torch.Generator().manual_seed(B + C + S + P))
+    want = x.permute(0, 2, 3, 1).reshape(B * S, P * C)
+    got = ops.seq_patches(x.to(DEV), torch.float32)
+    assert torch.equal(got.cpu(), want)
+    got16 = ops.seq_patches(x.to(DEV), torch.bfloat16)
+    assert torch.equal(got16.cpu(), want.bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,D,kin,has_cls", [(2, 12, 64, 3, True), (3, 50, 1024, 4, True), (2, 33, 192, 3, False), (5, 196, 768, 3, True),
+                                               (40, 196, 1024, 3, True)])
+def test_adaptive_pos_embedding_fwd_bwd(dtype, B, S, D, kin, has_cls):
+    """cat(cls, x) + cat(0, GELU(Linear(seq_ps))) (arch.py:311-321, :366-393) against fp32/fp64 torch on the same rounded inputs;
+    the gradient reductions run over more than one chunk of rows in the larger cases"""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(B * 131 + S * 7 + D + kin)
+    x = torch.randn(B * S, D, generator=gen)
+    sp = torch.cat([torch.randint(0, 224, (B, S, kin - 1), generator=gen).float(), 2.0 ** torch.randint(1, 6, (B, S, 1), generator=gen).float()], 2)
+    w = torch.randn(D, kin, generator=gen) * 0.02
+    bias = torch.randn(D, generator=gen) * 0.1
+    cls = torch.randn(D, generator=gen) if has_cls else None
+    dout = torch.randn(B, S + int(has_cls), D, generator=gen)
+    r = lambda t: None if t is None else t.to(dtype).double().requires_grad_(True)       # reference sees the same rounded inputs
+    xr, wr, br, cr = r(x), r(w), r(bias), r(cls)
+    pos = torch.nn.functional.gelu(sp.double() @ wr.t() + br)
+    tok = xr.view(B, S, D) + pos
+    want = torch.cat([cr.view(1, 1, D).expand(B, 1, D), tok], 1) if has_cls else tok
+    want.backward(dout.to(dtype).double())
+    dv = lambda t: None if t is None else t.to(DEV, dtype)
+    out = ops.adaptive_pos_fwd(dv(x), sp.to(DEV), dv(w), dv(bias), dv(cls), B, S, D)
+    tol = TOL[dtype]
+    assert rel_err(out.float().cpu(), want.detach().float()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    dx, dw, db, dc = ops.adaptive_pos_bwd(dv(dout), sp.to(DEV), dv(w), dv(bias), B, S, D, has_cls)
+    assert torch.equal(dx.view(B, S, D), dv(dout)[:, int(has_cls):])
+    assert rel_err(dw.cpu(), wr.grad.float()) < 1e-4 and rel_err(db.cpu(), br.grad.float()) < 1e-4
+    if has_cls:
+        assert rel_err(dc.cpu(), cr.grad.float()) < 1e-5
+    # accumulate bits: a second call with all three set doubles the sums
+    ops.adaptive_pos_bwd(dv(dout), sp.to(DEV), dv(w), dv(bias), B, S, D, has_cls, want_dx=False, dw=dw, dbias=db, dcls=dc, acc_bits=7)
+    assert rel_err(dw.cpu(), 2 * wr.grad.float()) < 1e-4 and rel_err(db.cpu(), 2 * br.grad.float()) < 1e-4
+    if has_cls:
+        assert rel_err(dc.cpu(), 2 * cr.grad.float()) < 1e-5

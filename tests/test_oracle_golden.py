@@ -91,6 +91,51 @@ def test_oracle_vit_small():
         assert rel_err(p.grad, g["g." + k]) < 2e-5, k
 
 
+ADAPTIVE_CASES = [("model_vit_adaptive.npz", dict(patch_size=8, in_chans=3, twoD=True, use_adaptive_pos_emb=True), 52),
+                  ("model_vit_adaptive_learnpos.npz", dict(patch_size=8, in_chans=3, twoD=True, use_adaptive_pos_emb=False), 53),
+                  ("model_vit_adaptive_3d.npz", dict(patch_size=4, in_chans=1, twoD=False, use_adaptive_pos_emb=True), 56)]
+
+
+@pytest.mark.parametrize("name,kw,seed", ADAPTIVE_CASES)
+def test_oracle_vit_adaptive_patching(name, kw, seed):
+    """VIT(adaptive_patching=True): LayerNorm-Linear-LayerNorm token embedding of pre-cut patches + position embedding from seq_ps"""
+    g = load_golden(name)
+    m = R.AdaptiveVIT(num_classes=5, embed_dim=64, depth=2, num_heads=2, fixed_length=12, **kw)
+    m.load_state_dict(det_state_dict(m, seed, keep=()))
+    out = m(g["x"], None, g["seq_ps"])
+    loss = torch.nn.CrossEntropyLoss()(out, g["labels"])
+    loss.backward()
+    assert rel_err(out, g["logits"]) < 1e-5 and abs(loss.item() - g["loss"].item()) < 1e-6
+    for k, p in m.named_parameters():
+        ref = g["g." + k]
+        if p.grad is None:
+            assert float(ref.abs().max()) == 0.0, k        # pos_embed is unused when the position embedding comes from seq_ps
+        else:
+            assert rel_err(p.grad, ref) < 2e-5, k
+
+
+@pytest.mark.parametrize("name,adaptive_pos,seed", [("model_mae_adaptive.npz", True, 58), ("model_mae_adaptive_learnpos.npz", False, 59)])
+def test_oracle_mae_adaptive_patching(name, adaptive_pos, seed):
+    """MAE(adaptive_patching=True): encoder and decoder positions from seq_ps (or learnt tables), target = the rearranged sequence"""
+    g = load_golden(name)
+    m = R.AdaptiveMAE(patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2, fixed_length=12, use_adaptive_pos_emb=adaptive_pos,
+                      mask_ratio=0.5, decoder_depth=1, decoder_embed_dim=32, decoder_num_heads=1)
+    m.load_state_dict(det_state_dict(m, seed, keep=()))
+    pred, mask = m(g["x"], None, g["seq_ps"], g["noise"])
+    target = g["x"].permute(0, 2, 3, 1).flatten(2)
+    loss = torch.nn.MSELoss()(pred, target)
+    loss.backward()
+    assert torch.equal(mask, g["mask"])
+    assert rel_err(pred, g["pred"]) < 1e-5 and abs(loss.item() - g["loss"].item()) < 1e-6
+    assert abs(R.masked_mse(pred, target, mask).item() - g["loss_masked"].item()) < 1e-6
+    for k, p in m.named_parameters():
+        ref = g["g." + k]
+        if p.grad is None:
+            assert float(ref.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, ref) < 2e-5, k
+
+
 def test_oracle_vit_tiny_config_T():
     """BASELINE configs[0]: ViT-Tiny/16, catsdogs tile 256x256, 2 classes (un-normalised 0..255 pixels)"""
     g = load_golden("model_vit_tiny_catsdogs.npz")

@@ -533,6 +533,59 @@ class TokensFn(torch.autograd.Function):
         return gx, g_cls, g_pos, None
 
 
+class SeqPatchesFn(torch.autograd.Function):
+    """einops 'b c s p -> b s (p c)' on the adaptively patched input (arch.py:466); the input is data, no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, cdtype):
+        xin = x if x.dtype == torch.float32 else x.float()
+        xin = xin if xin.is_contiguous() else xin.contiguous()
+        B, C, S, P = xin.shape
+        return ops.seq_patches(xin, cdtype).view(B, S, P * C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, None
+
+
+class AdaptivePosFn(torch.autograd.Function):
+    """VIT._pos_embed with use_adaptive_pos_emb (arch.py:366-393): cat(cls, x) + cat(0, GELU(Linear(seq_ps))).  The K = 3 | 4 Linear,
+    the GELU, the concatenation and the add are one kernel; backward recomputes the pre-activation from seq_ps."""
+
+    @staticmethod
+    def forward(ctx, x, seq_ps, w, bias, cls, cdtype):
+        xin = _as(x, cdtype)
+        B, S, D = xin.shape
+        sp = seq_ps if seq_ps.dtype == torch.float32 else seq_ps.float()
+        sp = sp if sp.is_contiguous() else sp.contiguous()
+        out = ops.adaptive_pos_fwd(xin.view(B * S, D), sp, compute_param(w, cdtype), compute_param(bias, cdtype),
+                                   compute_param(cls, cdtype).reshape(-1) if cls is not None else None, B, S, D)
+        ctx.save_for_backward(sp, w, bias, cls)
+        ctx.meta = (B, S, D, cdtype, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sp, w, bias, cls = ctx.saved_tensors
+        B, S, D, cdtype, in_dtype = ctx.meta
+        d = _as(dout, cdtype)
+        has_cls = cls is not None
+        tw, aw = grad_target(w)
+        tb, ab = grad_target(bias)
+        tc, ac = grad_target(cls) if has_cls else (None, False)
+        bits = (1 if aw else 0) | (2 if ab else 0) | (4 if ac else 0)
+        dx, dw, db, dc = ops.adaptive_pos_bwd(d, sp, compute_param(w, cdtype), compute_param(bias, cdtype), B, S, D, has_cls,
+                                              want_dx=ctx.needs_input_grad[0], dw=tw, dbias=tb,
+                                              dcls=tc.view(-1) if tc is not None else None, acc_bits=bits)
+        gx = _ret_grad(dx.view(B, S, D), in_dtype) if dx is not None else None
+        g_w = None if aw else (tw if tw is not None else dw)
+        g_b = None if ab else (tb if tb is not None else db)
+        g_c = None
+        if has_cls and not ac:
+            g_c = tc if tc is not None else dc.view(cls.shape)
+        return gx, None, g_w, g_b, g_c, None
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """nn.CrossEntropyLoss()(logits, labels), mean reduction (train_class_simple.py:24-30); fp32 loss scalar."""
 

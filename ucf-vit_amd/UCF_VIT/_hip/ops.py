@@ -276,6 +276,69 @@ def tokens_bwd(dout, B, Lp, D, has_cls, want_pos, dpos=None, dcls=None, accumula
     return dpatches, dpos, dcls
 
 
+# ------------------------------------------------------------------------------------------------ adaptive patching
+def seq_patches(x, dtype):
+    """x fp32 [B, C, S, P] -> rows [B*S, P*C] in `dtype` (einops 'b c s p -> b s (p c)', arch.py:466)"""
+    L = _l.load()
+    _chk(x, "seq_patches.x")
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise TypeError("seq_patches: x must be fp32 [B, C, S, P]")
+    B, C, S, P = x.shape
+    out = torch.empty((B * S, P * C), dtype=dtype, device=x.device)
+    _l.check(L.ucfvit_seq_patches(x.data_ptr(), out.data_ptr(), B, C, S, P, _DT[dtype], _stream()), "ucfvit_seq_patches")
+    return out
+
+
+def _chk_seq_ps(seq_ps, B, S, name):
+    _chk(seq_ps, name)
+    if seq_ps.dtype != torch.float32 or seq_ps.dim() != 3 or seq_ps.shape[0] != B or seq_ps.shape[1] != S or seq_ps.shape[2] not in (3, 4):
+        raise ValueError(f"{name}: seq_ps must be fp32 [B={B}, S={S}, 3|4], got {tuple(seq_ps.shape)} {seq_ps.dtype}")
+    return seq_ps.shape[2]
+
+
+def adaptive_pos_fwd(x2, seq_ps, w, bias, cls, B, S, D):
+    """out [B, S+pre, D] = cat(cls, x) + cat(0, GELU(seq_ps w^T + bias))"""
+    L = _l.load()
+    _chk(x2, "adaptive_pos.x"), _chk(w, "adaptive_pos.w"), _chk(bias, "adaptive_pos.bias")
+    kin = _chk_seq_ps(seq_ps, B, S, "adaptive_pos.seq_ps")
+    if tuple(x2.shape) != (B * S, D) or tuple(w.shape) != (D, kin) or bias.numel() != D or w.dtype != x2.dtype or bias.dtype != x2.dtype:
+        raise ValueError("adaptive_pos_fwd: shape / dtype mismatch")
+    pre = 0 if cls is None else 1
+    if cls is not None and (cls.numel() != D or cls.dtype != x2.dtype):
+        raise ValueError("adaptive_pos_fwd: cls must hold D values of the compute dtype")
+    out = torch.empty((B, S + pre, D), dtype=x2.dtype, device=x2.device)
+    _l.check(L.ucfvit_adaptive_pos_fwd(x2.data_ptr(), seq_ps.data_ptr(), w.data_ptr(), bias.data_ptr(), _p(cls), out.data_ptr(), B, S, D, kin,
+                                       pre, dt(x2), _stream()), "ucfvit_adaptive_pos_fwd")
+    return out
+
+
+def adaptive_pos_bwd(dout, seq_ps, w, bias, B, S, D, has_cls, want_dx=True, dw=None, dbias=None, dcls=None, acc_bits=0):
+    """returns (dx [B*S, D] or None, dw fp32 [D, kin], dbias fp32 [D], dcls fp32 [D] or None); given outputs are written in place,
+    acc_bits (1 dw, 2 dbias, 4 dcls) selects += for them"""
+    L = _l.load()
+    _chk(dout, "adaptive_pos_bwd.dout")
+    kin = _chk_seq_ps(seq_ps, B, S, "adaptive_pos_bwd.seq_ps")
+    pre = 1 if has_cls else 0
+    if tuple(dout.shape) != (B, S + pre, D) or tuple(w.shape) != (D, kin) or w.dtype != dout.dtype:
+        raise ValueError("adaptive_pos_bwd: shape / dtype mismatch")
+    dev = dout.device
+    dx = torch.empty((B * S, D), dtype=dout.dtype, device=dev) if want_dx else None
+    if dw is None:
+        dw = torch.empty((D, kin), dtype=torch.float32, device=dev)
+    if dbias is None:
+        dbias = torch.empty(D, dtype=torch.float32, device=dev)
+    if has_cls and dcls is None:
+        dcls = torch.empty(D, dtype=torch.float32, device=dev)
+    for t, n in ((dw, D * kin), (dbias, D), (dcls, D)):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous()):
+            raise ValueError("adaptive_pos_bwd: gradient outputs must be contiguous fp32 of the parameter's size")
+    ws = workspace(L.ucfvit_adaptive_pos_bwd_workspace(B, S, D, kin, pre, dt(dout)), dev)
+    _l.check(L.ucfvit_adaptive_pos_bwd(dout.data_ptr(), seq_ps.data_ptr(), w.data_ptr(), bias.data_ptr(), _p(dx), dw.data_ptr(), dbias.data_ptr(),
+                                       _p(dcls) if has_cls else None, B, S, D, kin, pre, acc_bits, ws.data_ptr(), dt(dout), _stream()),
+             "ucfvit_adaptive_pos_bwd")
+    return dx, dw, dbias, (dcls if has_cls else None)
+
+
 def cross_entropy(logits, labels, grad_scale=1.0, want_grad=True):
     """returns (loss fp32 scalar tensor, dlogits or None, row_loss)"""
     L = _l.load()
@@ -356,12 +419,17 @@ def unshuffle_bwd(dout, ids_restore, R, want_pos, dmask=None, dpos=None, accumul
 
 
 def patch_mse(pred, img, p, mask=None, grad_scale=1.0, want_grad=True):
-    """pred [B,L,P]; img fp32 NCHW(D); mask fp32 [B,L] or None -> (loss scalar fp32, dpred or None)"""
+    """pred [B,L,P]; img fp32 NCHW(D) (p = patch size) or the adaptive token sequence [B,C,S,P] (p = None); mask fp32 [B,L] or None
+    -> (loss scalar fp32, dpred or None)"""
     L = _l.load()
     _chk(pred, "patch_mse.pred"), _chk(img, "patch_mse.img")
     B, C = img.shape[0], img.shape[1]
     sp = list(img.shape[2:])
     nd = len(sp)
+    if p is None:       # adaptive token sequence x [B, C, S, P]: target 'b c s p -> b s (p c)'
+        if nd != 2 or tuple(pred.shape) != (B, sp[0], C * sp[1]):
+            raise ValueError(f"patch_mse: sequence target [B,C,S,P]={tuple(img.shape)} does not match pred {tuple(pred.shape)}")
+        nd, p, sp = 1, sp[1], [sp[0]]
     dims = (ctypes.c_int64 * 3)(*(sp + [1] * (3 - nd)))
     loss = torch.empty((), dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None

@@ -239,16 +239,26 @@ class VIT(nn.Module):
         return nn.Parameter(torch.zeros(1, len(self.default_vars), dim), requires_grad=True), var_map
 
     def _embed_tokens(self, x, variables):
-        if self.use_varemb or (self.adaptive_patching and not self.sqrt_len_method):
-            raise NotImplementedError("use_varemb / adaptive_patching front ends are 'next' rows (SURVEY.md §8f); "
-                                      "the HIP hot path covers image input with adaptive_patching=False, use_varemb=False")
+        if self.use_varemb:
+            raise NotImplementedError("the use_varemb front end (per-variable embedding + variable aggregation) is a 'next' row "
+                                      "(SURVEY.md §8f); the HIP path covers use_varemb=False")
+        if self.adaptive_patching and not self.sqrt_len_method:
+            # reference :465-467: x [B, C, S, P] arrives already cut into S resized patches -> rows (p c) -> LN, Linear, LN
+            if x.dim() != 4 or x.shape[1] * x.shape[3] != self.patch_dim:
+                raise ValueError(f"adaptive_patching expects x [B, C={self.in_chans}, S, P={self.patch_dim_woc}], got {tuple(x.shape)}")
+            return self.token_embeds(HF.SeqPatchesFn.apply(x, _cd(self)))
         return self.token_embeds(x)
 
     def _pos_embed(self, x: torch.Tensor, seq_ps) -> torch.Tensor:
+        if self.pos_embed is None:
+            return x.view(x.shape[0], -1, x.shape[-1])      # reference :367-368 returns before the class token is attached
+        if self.pos_drop.p > 0.0 and self.training:
+            raise NotImplementedError("pos_drop_rate > 0 is not on the HIP hot path")
         if self.use_adaptive_pos_emb:
-            raise NotImplementedError("use_adaptive_pos_emb is a 'next' row (SURVEY.md §8f rank 1)")
-        if self.pos_embed is None and self.cls_token is None:
-            return x.view(x.shape[0], -1, x.shape[-1])
+            if seq_ps is None:
+                raise ValueError("use_adaptive_pos_emb needs seq_ps [B, S, 3|4] (position and size of every token)")
+            lin = self.adaptive_pos_dep_emb[0]
+            return HF.AdaptivePosFn.apply(x, seq_ps, lin.weight, lin.bias, self.cls_token, _cd(self))
         if self.pos_drop.p > 0.0 and self.training:
             raise NotImplementedError("pos_drop_rate > 0 is not on the HIP hot path")
         return HF.TokensFn.apply(x, self.cls_token, self.pos_embed, _cd(self))
@@ -363,12 +373,16 @@ class MAE(VIT):
         return HF.RandomMaskFn.apply(sequence, noise, len_keep)
 
     def mask_head(self, x: torch.Tensor, ids_restore, seq_ps):
-        if self.use_adaptive_pos_emb:
-            raise NotImplementedError("use_adaptive_pos_emb is a 'next' row (SURVEY.md §8f rank 1)")
         if not self.linear_decoder:
             x = self.decoder_embed(x)
-        x = HF.UnshuffleFn.apply(x, self.mask_token, ids_restore, None if self.linear_decoder else self.decoder_pos_embed, _cd(self))
+        pos = None if (self.linear_decoder or self.use_adaptive_pos_emb) else self.decoder_pos_embed
+        x = HF.UnshuffleFn.apply(x, self.mask_token, ids_restore, pos, _cd(self))
         if not self.linear_decoder:
+            if self.use_adaptive_pos_emb:           # reference :693-697: decoder positions from seq_ps as well (no class token here)
+                if seq_ps is None:
+                    raise ValueError("use_adaptive_pos_emb needs seq_ps [B, S, 3|4] (position and size of every token)")
+                lin = self.decoder_adaptive_pos_dep_emb[0]
+                x = HF.AdaptivePosFn.apply(x, seq_ps, lin.weight, lin.bias, None, _cd(self))
             x = self.decoder_norm(self.decoder_blocks(x))
         return self.decoder_pred(x)
 

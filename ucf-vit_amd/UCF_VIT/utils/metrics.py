@@ -18,5 +18,11 @@ def patch_mse_loss(pred, data, patch_size, mask=None):
     return HF.patch_mse(pred, data, patch_size, mask)
 
 
+def seq_mse_loss(pred, seq, mask=None):
+    """MSE(pred, rearrange(seq, 'b c s p -> b s (p c)')) for adaptively patched input (reference train_masked_simple.py:24-32),
+    target never materialised; mask given -> masked_mse semantics."""
+    return HF.patch_mse(pred, seq, None, mask)
+
+
 def cross_entropy_loss(logits, labels):
     return HF.cross_entropy(logits, labels)

@@ -311,7 +311,9 @@ struct PatchGeom {
 __device__ __forceinline__ float patch_target(const float* __restrict__ img, const PatchGeom& g, int64_t b, int l, int e) {
     const int c = e % g.C;
     int s = e / g.C;
-    if (g.nd == 2) {
+    if (g.nd == 1) {  // pre-cut token sequence x[B][C][S][P]: target row l = 'b c s p -> b s (p c)' (train_masked_simple.py:29)
+        return img[((b * g.C + c) * (int64_t)g.L + l) * g.p + s];
+    } else if (g.nd == 2) {
         const int pw = s % g.p, ph = s / g.p;
         const int w = l % g.gw, h = l / g.gw;
         return img[((b * g.C + c) * g.H + (h * g.p + ph)) * (int64_t)g.W + (w * g.p + pw)];
@@ -685,10 +687,13 @@ extern "C" int ucfvit_unshuffle_bwd(const void* dout, const int64_t* ids_restore
 extern "C" int ucfvit_patch_mse(const void* pred, const float* img, const float* mask, float* loss, void* dpred, int64_t B, int64_t C,
                                 const int64_t* dims, int nd, int64_t p, float grad_scale, float* workspace, int dtype, void* stream) {
     UCF_CHECK_ARG(pred && img && loss && workspace && dims, "ucfvit_patch_mse: null pointer");
-    UCF_CHECK_ARG(nd == 2 || nd == 3, "ucfvit_patch_mse: nd must be 2 or 3");
+    UCF_CHECK_ARG(nd == 1 || nd == 2 || nd == 3, "ucfvit_patch_mse: nd must be 1 (token sequence), 2 or 3");
     UCF_CHECK_ARG(DTYPE_OK(dtype), "ucfvit_patch_mse: bad dtype %d", dtype);
     UCF_CHECK_ARG(B > 0 && C > 0 && p > 0, "ucfvit_patch_mse: bad sizes");
-    for (int i = 0; i < nd; ++i) UCF_CHECK_ARG(dims[i] > 0 && dims[i] % p == 0, "ucfvit_patch_mse: image dim %d not a multiple of p", i);
+    if (nd == 1)
+        UCF_CHECK_ARG(dims[0] > 0 && dims[0] < (1ll << 31) && C * p < (1ll << 31), "ucfvit_patch_mse: bad sequence length");
+    else
+        for (int i = 0; i < nd; ++i) UCF_CHECK_ARG(dims[i] > 0 && dims[i] % p == 0, "ucfvit_patch_mse: image dim %d not a multiple of p", i);
     PatchGeom g;
     g.C = (int)C;
     g.H = (int)dims[0];
@@ -701,6 +706,11 @@ extern "C" int ucfvit_patch_mse(const void* pred, const float* img, const float*
     g.gz = nd == 3 ? g.Z / g.p : 1;
     g.L = g.gh * g.gw * g.gz;
     g.P = (int)(C * p * p * (nd == 3 ? p : 1));
+    if (nd == 1) {  // dims = {S}, p = pixels per token and channel
+        g.H = g.W = g.Z = g.gh = g.gw = g.gz = 1;
+        g.L = (int)dims[0];
+        g.P = (int)(C * p);
+    }
     const int64_t total = B * g.L * g.P;
     hipStream_t s = (hipStream_t)stream;
     int nb = (int)((total + 256 * 64 - 1) / (256 * 64));

@@ -43,12 +43,14 @@ def model_args(conf):
     a, d = conf["model"]["net"]["init_args"], conf["data"]
     dataset = d["dataset"]
     chans = 1 if d.get("single_channel", False) else max(1, d["num_channels_used"][dataset])
-    if a.get("adaptive_patching", False) or a.get("use_varemb", False):
-        raise NotImplementedError("adaptive_patching / use_varemb configs are 'next' rows (SURVEY.md §8f); set them False")
+    if a.get("use_varemb", False):
+        raise NotImplementedError("use_varemb configs are a 'next' row (SURVEY.md §8f); set it False")
+    adaptive = bool(a.get("adaptive_patching", False))
     return dict(img_size=a["tile_size"], patch_size=a["patch_size"], in_chans=chans, embed_dim=a["embed_dim"], depth=a["depth"],
                 num_heads=a["num_heads"], mlp_ratio=a["mlp_ratio"], drop_path_rate=a.get("drop_path", 0.0), twoD=a["twoD"],
                 default_vars=a["default_vars"], single_channel=d.get("single_channel", False), use_varemb=False,
-                adaptive_patching=False, fixed_length=a.get("fixed_length", 4096)), a, d
+                adaptive_patching=adaptive, fixed_length=a.get("fixed_length", 4096),
+                use_adaptive_pos_emb=bool(a.get("use_adaptive_pos_emb", False)) and adaptive), a, d
 
 
 class SyntheticLoader:
@@ -68,6 +70,29 @@ class SyntheticLoader:
             else:
                 label = torch.randint(0, max(self.num_classes, 1), (self.shape[0],), generator=g)
             yield data.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
+
+
+class SyntheticSeqLoader:
+    """per-rank synthetic batches shaped like the reference's adaptive-patching dataloader output (train_class_simple.py:322-337):
+    seq fp32 [B, C, S, P] (S = fixed_length resized patches of P = p^nd pixels), seq_ps fp32 [B, S, 3|4] = (size, position...),
+    label.  The quadtree / octree patcher itself is a data-pipeline 'next' row."""
+
+    def __init__(self, batch_size, in_chans, img_size, patch_size, fixed_length, num_classes, iters, device, seed):
+        nd = len(img_size)
+        self.shape = (batch_size, in_chans, fixed_length, patch_size ** nd)
+        self.nd, self.img = nd, min(img_size)
+        self.num_classes, self.iters, self.device, self.seed = num_classes, iters, device, seed
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        B, _, S, _ = self.shape
+        for _ in range(self.iters):
+            seq = torch.randint(0, 256, self.shape, generator=g).float()
+            size = 2.0 ** torch.randint(1, 6, (B, S, 1), generator=g).float()
+            pos = torch.randint(0, self.img, (B, S, self.nd), generator=g).float()
+            label = torch.randint(0, max(self.num_classes, 1), (B,), generator=g)
+            dev = self.device
+            yield seq.to(dev, non_blocking=True), torch.cat([size, pos], dim=-1).to(dev, non_blocking=True), label.to(dev, non_blocking=True)
 
 
 def save_checkpoint(conf, epoch, model, optimizer, scheduler, loss_list, rank):

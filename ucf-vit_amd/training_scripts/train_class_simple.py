@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-from _common import (SyntheticLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
+from _common import (SyntheticLoader, SyntheticSeqLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
                      save_checkpoint)
 from UCF_VIT.simple.arch import VIT
 from UCF_VIT.utils.fused_attn import FusedAttn
@@ -31,14 +31,20 @@ def main(device, local_rank, rank, world):
     scheduler = configure_scheduler(optimizer, int(m["warmup_steps"]), int(m["max_steps"]), float(m["warmup_start_lr"]), float(m["eta_min"]))
     epoch_start, loss_list = maybe_resume(conf, net, optimizer, scheduler)
     variables = d["dict_in_variables"][d["dataset"]]
-    loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], d["num_classes"], iters_per_epoch(conf), device, 1234 + rank)
+    if margs["adaptive_patching"]:     # reference :322-337: the batch carries the token sequence and (size, position) per token
+        seq_loader = SyntheticSeqLoader(d["batch_size"], margs["in_chans"], margs["img_size"], margs["patch_size"], margs["fixed_length"],
+                                        d["num_classes"], iters_per_epoch(conf), device, 1234 + rank)
+        loader = lambda: ((seq, label, seq_ps) for seq, seq_ps, label in seq_loader)
+    else:
+        img_loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], d["num_classes"], iters_per_epoch(conf), device, 1234 + rank)
+        loader = lambda: ((data, label, None) for data, label in img_loader)
     for epoch in range(epoch_start, conf["trainer"]["max_epochs"]):
         model.train()
         epoch_loss = torch.zeros((), device=device)
         epoch_acc = torch.zeros((), device=device)
         timer = StepTimer()
-        for batch_idx, (data, label) in enumerate(loader):
-            loss, output = training_step(data, variables, label, net, None)
+        for batch_idx, (data, label, seq_ps) in enumerate(loader()):
+            loss, output = training_step(data, variables, label, net, seq_ps)
             epoch_acc += (output.argmax(dim=1) == label).float().mean()
             epoch_loss += loss.detach()
             loss.backward()

@@ -5,11 +5,11 @@ import sys
 
 import torch
 
-from _common import (SyntheticLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
+from _common import (SyntheticLoader, SyntheticSeqLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
                      save_checkpoint)
 from UCF_VIT.simple.arch import MAE
 from UCF_VIT.utils.fused_attn import FusedAttn
-from UCF_VIT.utils.metrics import patch_mse_loss
+from UCF_VIT.utils.metrics import patch_mse_loss, seq_mse_loss
 from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
 from UCF_VIT._hip.ddp import HipDataParallel
 
@@ -18,6 +18,12 @@ def training_step(data, variables, net, patch_size, twoD, loss_fn):
     output, mask = net(data, variables, None)
     # target = patchify(data) is never materialised: the loss kernel reads the image in place (misc.py:14-33 layout)
     return patch_mse_loss(output, data, patch_size, mask if loss_fn == "maskMSE" else None), output, mask
+
+
+def training_step_adaptive(seq, variables, net, loss_fn, seq_ps):
+    """reference :24-32: target = rearrange(seq, 'b c s p -> b s (p c)'), read in place by the loss kernel"""
+    output, mask = net(seq, variables, seq_ps)
+    return seq_mse_loss(output, seq, mask if loss_fn == "maskMSE" else None), output, mask
 
 
 def main(device, local_rank, rank, world):
@@ -34,13 +40,22 @@ def main(device, local_rank, rank, world):
     epoch_start, loss_list = maybe_resume(conf, net, optimizer, scheduler)
     variables = d["dict_in_variables"][d["dataset"]]
     loss_fn = conf["trainer"].get("loss_fn", a.get("loss_fn", "MSE"))
-    loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], 0, iters_per_epoch(conf), device, 1234 + rank)
+    if margs["adaptive_patching"]:
+        seq_loader = SyntheticSeqLoader(d["batch_size"], margs["in_chans"], margs["img_size"], margs["patch_size"], margs["fixed_length"], 0,
+                                        iters_per_epoch(conf), device, 1234 + rank)
+        loader = lambda: ((seq, seq_ps) for seq, seq_ps, _ in seq_loader)
+    else:
+        img_loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], 0, iters_per_epoch(conf), device, 1234 + rank)
+        loader = lambda: ((data, None) for data, _ in img_loader)
     for epoch in range(epoch_start, conf["trainer"]["max_epochs"]):
         model.train()
         epoch_loss = torch.zeros((), device=device)
         timer = StepTimer()
-        for data, _ in loader:
-            loss, _, _ = training_step(data, variables, net, margs["patch_size"], margs["twoD"], loss_fn)
+        for data, seq_ps in loader():
+            if margs["adaptive_patching"]:
+                loss, _, _ = training_step_adaptive(data, variables, net, loss_fn, seq_ps)
+            else:
+                loss, _, _ = training_step(data, variables, net, margs["patch_size"], margs["twoD"], loss_fn)
             epoch_loss += loss.detach()
             loss.backward()
             optimizer.step()

@@ -35,6 +35,8 @@ def training_step(data, variables, label, net):
 def main(device, local_rank, rank, world):
     conf = load_config(sys.argv[1])
     margs, a, d = model_args(conf)
+    if margs["adaptive_patching"]:
+        raise NotImplementedError("UNETR on adaptively patched input (x_seq + sqrt_len grids) is a 'next' row (SURVEY.md §8f); set adaptive_patching False")
     m = conf["model"]
     model = UNETR(num_classes=d["num_classes"], class_token=False, weight_init='', linear_decoder=a.get("linear_decoder", False),
                   feature_size=a.get("feature_size", 16), skip_connection=a.get("skip_connection", True),
