@@ -36,6 +36,7 @@ class GemmDesc(Structure):
 _P, _I64, _I, _F = c_void_p, c_int64, c_int, c_float
 SIGNATURES = {
     "ucfvit_abi_version": (c_int, []),
+    "ucfvit_mfma_probe": (_I64, [_P, _I, _P]),
     "ucfvit_last_error": (c_char_p, []),
     "ucfvit_gemm_workspace": (c_int64, [POINTER(GemmDesc)]),
     "ucfvit_gemm": (c_int, [POINTER(GemmDesc), _P]),

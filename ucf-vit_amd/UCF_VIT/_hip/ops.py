@@ -53,6 +53,16 @@ def workspace(nbytes, device):
     return ws
 
 
+def mfma_probe(iters=20000):
+    """diagnostic: one launch of a pure bf16 MFMA stream on the current stream; returns the FLOPs it executes"""
+    L = _l.load()
+    sink = workspace(1024, torch.device("cuda", torch.cuda.current_device()))
+    flops = L.ucfvit_mfma_probe(sink.data_ptr(), int(iters), _stream())
+    if flops < 0:
+        _l.check(int(flops), "ucfvit_mfma_probe")
+    return flops
+
+
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None, residual=None, act=ACT_NONE,
          aux_in=None, aux_out=None, accumulate=False, alpha=1.0, c_colsum=None, c_colsum_accumulate=False):

@@ -604,6 +604,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
             if constexpr (LB == UCFVIT_LAYOUT_KS) { _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = ks_frag_value(kb[j]); } \
         }                                                                                      \
     } while (0)
+#ifdef UCFVIT_DBG_NOMFMA   /* timing experiment only (wrong results): fragments are consumed, 2 of 32 MFMAs issued */
+#define PP_COMPUTE()                                                                           \
+    do {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(fa[i]));          \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(fb[j]));          \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0], acc[0][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1], acc[1][1], 0, 0, 0); \
+    } while (0)
+#else
 #define PP_COMPUTE()                                                                           \
     do {                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                         \
@@ -612,6 +621,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                         \
     } while (0)
+#endif
 #define PP_ISSUE_ONE(LAY_, BR_, base_, ld_, off_, nbase_, nld_, r0n_, Rn_, ldsoff_, kt_)         \
     do {                                                                                       \
         char* nb = smem + ((it + 1) & 1) * BUF + (ldsoff_);                                    \
@@ -642,11 +652,19 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
             if constexpr (LB == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksB));   // recomputed, not hoisted into 12 live VGPRs
             PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) ...
             PP_ISSUE_A(kt);                 // ... and of its OWN rows of the next A tile (that region was last read in MEM(c1) of the tile before)
+#ifdef UCFVIT_DBG_NOREAD   /* timing experiment only (wrong results): fragment reads on the first K-tile only */
+            if (kt == 0) PP_READ(bufA, bufB, 0);
+#else
             PP_READ(bufA, bufB, 0);
+#endif
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c0)
             PP_BARRIER();
+#ifdef UCFVIT_DBG_NOREAD
+            if (kt == 0) PP_READ(bufA, bufB, 1);
+#else
             PP_READ(bufA, bufB, 1);         // MEM(c1): fragment reads only
+#endif
             if (grp == 1) PP_WAIT_B();      // G1's B half (issued 2 intervals ago) must be visible before G0's next MEM(c0); its A pieces stay in flight
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c1)
