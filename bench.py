@@ -274,7 +274,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} train step (fwd+bwd+AdamW), synthetic U{{0..255}} images resident in HBM",
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+                       "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, RCCL, overlapped with backward") if world > 1 else "none (1 rank)"},
             "roofline": {"bound": "mfma", "kernel": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
                                              "weight-gradient launch of the timed region)" % args.dtype,
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

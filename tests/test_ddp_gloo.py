@@ -70,7 +70,7 @@ def test_reducer_two_ranks_gloo(bucket_mb, min_buckets):
         assert keys_ok and nb >= min_buckets
 
 
-def _hip_dp_worker(rank, world, port, q):
+def _hip_dp_worker(rank, world, port, q, reduce_dtype=None):
     for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -89,7 +89,7 @@ def _hip_dp_worker(rank, world, port, q):
         m = VIT(**kw)
         m.load_state_dict(det_state_dict(m, 100 + rank))        # different per rank: the wrap broadcasts rank 0's weights
         m = m.to("cuda:0")
-        ddp = HipDataParallel(m, bucket_mb=0.05)
+        ddp = HipDataParallel(m, bucket_mb=0.05, reduce_dtype=reduce_dtype)
         opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 0.0)
         xs = [det_tensor((2, 3, 32, 32), 10 + r) for r in range(world)]
         ys = [torch.tensor([r % 5, (2 * r + 1) % 5]) for r in range(world)]
@@ -103,7 +103,10 @@ def _hip_dp_worker(rank, world, port, q):
         cross_entropy_loss(out, ys[rank].to("cuda:0")).backward()
         torch.cuda.synchronize()
         from conftest import rel_err
-        bad = [k for (k, p), e in zip(m.named_parameters(), exp) if rel_err(p.grad, e / world) > 1e-3]
+        tol = 1e-3 if reduce_dtype is None else 1e-2           # bf16 transport: each rank's gradient and the mean are rounded to 8 bits
+        bad = [k for (k, p), e in zip(m.named_parameters(), exp) if rel_err(p.grad, e / world) > tol]
+        if reduce_dtype == "bf16":
+            bad += [k + " (not a bf16 value)" for k, p in m.named_parameters() if not torch.equal(p.grad, p.grad.bfloat16().float())]
         opt.step()
         opt.zero_grad()
         # after an identical update every rank must hold identical weights
@@ -114,6 +117,24 @@ def _hip_dp_worker(rank, world, port, q):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_data_parallel_bf16_gradient_transport_two_ranks():
+    """reduce_dtype = bf16 (the reference's MixedPrecision(reduce_dtype=bfloat16) policy, train_masked_fsdp.py:375-381): the mean
+    gradient arrives as bf16 values within 1e-2 of the fp32 mean, and the ranks stay bit-identical after the optimizer step"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_dp_worker, args=(r, 2, 29573, q, "bf16")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, same, flat in res:
+        assert not bad, f"rank {rank}: gradient mismatch in {bad}"
+        assert same and flat
 
 
 @pytest.mark.gpu

@@ -314,8 +314,10 @@ def test_state_dict_layout_matches_reference_listing():
         assert k in mk
 
 
-def test_hip_data_parallel_world1_nccl():
-    """the RCCL reducer path (flat-buffer buckets, AVG all-reduce on the nccl backend, end-of-backward stream wait) on one rank"""
+@pytest.mark.parametrize("reduce_dtype", [None, torch.bfloat16])
+def test_hip_data_parallel_world1_nccl(reduce_dtype):
+    """the RCCL reducer path (flat-buffer buckets, AVG all-reduce on the nccl backend, end-of-backward stream wait) on one rank;
+    with bf16 gradient transport (staging buffer, cast back at the end of backward) the gradients are the bf16-rounded ones"""
     import os
     import torch.distributed as dist
     from UCF_VIT.simple.arch import VIT
@@ -324,12 +326,13 @@ def test_hip_data_parallel_world1_nccl():
     from UCF_VIT._hip.ddp import HipDataParallel
     g = load_golden("model_vit_small.npz")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = "29533" if reduce_dtype is None else "29534"
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         m = build(VIT, VIT_KW, 21)
-        ddp = HipDataParallel(m, bucket_mb=0.05)
+        ddp = HipDataParallel(m, bucket_mb=0.05, reduce_dtype=reduce_dtype)
         assert len(ddp.buckets) >= 3
+        assert ddp.reduce_dtype() == (reduce_dtype or torch.float32)
         opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 1e-2)
         for _ in range(2):
             out = ddp(g["x"].to(DEV), VARS, None)
@@ -337,7 +340,9 @@ def test_hip_data_parallel_world1_nccl():
             loss.backward()
             if _ == 0:
                 for k, p in m.named_parameters():
-                    assert rel_err(p.grad, g["g." + k]) < 1e-3, k
+                    assert rel_err(p.grad, g["g." + k]) < (1e-3 if reduce_dtype is None else 8e-3), k
+                    if reduce_dtype is not None:
+                        assert torch.equal(p.grad, p.grad.bfloat16().float()), k
             opt.step()
             opt.zero_grad()
         assert "_flat" in opt.state

@@ -11,13 +11,23 @@ callback makes the compute stream wait for the outstanding collectives (no host 
 MI355X note (8 GPUs fully connected by xGMI, ~153 GB/s per link): bucket size is a trade between per-collective launch
 latency and overlap; 32 MiB fp32 buckets keep ~40 collectives per ViT-L step, each far above the latency-bound regime.
 
+Gradient transport dtype: fp32 in fp32 mode (torch DDP of the train_*_simple.py scripts); bf16 when the model computes in bf16,
+mirroring the reference's bf16 policy `MixedPrecision(param_dtype=reduce_dtype=buffer_dtype=bfloat16)`
+(training_scripts/train_masked_fsdp.py:375-381): the bucket is cast into a persistent bf16 staging buffer, all-reduced (mean)
+there and cast back into the fp32 gradient buffer at the end of backward.  Half the xGMI bytes (ViT-L: 0.61 instead of 1.22 GB
+per step and rank) and half the time RCCL's workgroups hold CUs that the persistent GEMM grids want.  `reduce_dtype=` or
+UCFVIT_DDP_REDUCE_DTYPE=fp32|bf16 override the default.
+
 Requirements: call optimizer.zero_grad() (set_to_none or not) every step, as the reference loop does.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 from . import functional as _HF
+from . import ops as _ops
 from .params import ensure_store
 
 
@@ -41,9 +51,16 @@ class _FlatGrads:
 
 
 class HipDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=32, broadcast_from=0):
+    def __init__(self, module, process_group=None, bucket_mb=32, broadcast_from=0, reduce_dtype=None):
         super().__init__()
         self.module = module
+        rd = reduce_dtype if reduce_dtype is not None else os.environ.get("UCFVIT_DDP_REDUCE_DTYPE")
+        if isinstance(rd, str):
+            rd = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[rd.lower()]
+        if rd not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("HipDataParallel: reduce_dtype must be torch.float32 or torch.bfloat16")
+        self._reduce_dtype = rd          # None: follow the module's compute dtype (looked up when the first bucket is launched)
+        self._comm = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         first = next(module.parameters())
@@ -120,22 +137,42 @@ class HipDataParallel(nn.Module):
             if self._pending[b] >= 0:
                 self._launch(b)
 
+    def reduce_dtype(self):
+        if not self._hip:
+            return torch.float32        # plain-module (CPU test) path
+        if self._reduce_dtype is not None:
+            return self._reduce_dtype
+        return torch.bfloat16 if getattr(self.module, "compute_dtype", torch.float32) == torch.bfloat16 else torch.float32
+
+    def _staging(self, lo, hi):
+        if self._comm is None:
+            self._comm = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
+        return self._comm[lo:hi]
+
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         view = self.flat_g[lo:hi]
+        bf16 = self.reduce_dtype() == torch.bfloat16
         if self._hip and dist.get_backend(self.pg) != "gloo":
-            w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)      # RCCL, its own HIP stream
+            if bf16:
+                c = _ops.cast(view, self._staging(lo, hi))                                      # compute stream; RCCL waits for it
+                w = dist.all_reduce(c, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+                self._works.append((w, lo, hi))
+            else:
+                w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)   # RCCL, its own HIP stream
+                self._works.append((w, None, None))
         elif self._hip:
             # test transport (several ranks sharing one GPU cannot use RCCL): host-staged, synchronous
             h = view.cpu()
+            if bf16:
+                h = h.bfloat16().float()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
-            view.copy_(h.div_(self.world))
-            self._pending[b] = -(1 << 30)
-            return
+            h.div_(self.world)
+            view.copy_(h.bfloat16().float() if bf16 else h)
         else:
             view.div_(self.world)
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._works.append(w)
+            self._works.append((w, None, None))
         self._pending[b] = -(1 << 30)
 
     def _finish(self):
@@ -146,8 +183,10 @@ class HipDataParallel(nn.Module):
         for b in range(len(self.buckets)):
             if self._pending[b] >= 0:
                 self._launch(b)
-        for w in self._works:
+        for w, lo, hi in self._works:
             w.wait()          # compute stream waits for the RCCL stream; no host sync on the nccl backend
+            if lo is not None:
+                _ops.cast(self._comm[lo:hi], self.flat_g[lo:hi])      # bf16 mean back into the fp32 gradient buffer
         self._works = []
         self._callback_queued = False
 
