@@ -113,6 +113,93 @@ def test_mae_adaptive_patching_vs_reference(name, adaptive_pos, seed, dtype, tol
             assert rel_err(p.grad, ref) < tol, k
 
 
+def _check_grads_vs_golden(m, g, tol):
+    for k, p in m.named_parameters():
+        ref = g["g." + k]
+        if float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert p.grad is not None, k
+            assert rel_err(p.grad, ref) < tol, k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_vit_sqrt_len_method_3d_vs_reference(dtype, tol):
+    """adaptive patching as train_unetr_simple.py:43-49 / train_sap_simple.py:28-43 use it (sqrt_len_method=True): the token sequence
+    reshaped into a pseudo volume goes through the patch-embedding convolution (im2col + GEMM), positions come from seq_ps [B, S, 4]"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    g = load_golden("model_vit_sqrtlen_3d.npz")
+    m = VIT(img_size=[16, 16, 16], patch_size=4, in_chans=1, num_classes=5, embed_dim=96, depth=2, num_heads=3, adaptive_patching=True,
+            fixed_length=8, twoD=False, use_adaptive_pos_emb=True, sqrt_len_method=True, class_token=False)
+    m.load_state_dict(det_state_dict(m, 62, keep=()))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    out = m(g["x"].to(DEV), VARS, g["seq_ps"].to(DEV))
+    assert tuple(out.shape) == (2, 8, 5)
+    loss = cross_entropy_loss(out.flatten(0, 1), g["labels"].to(DEV))
+    loss.backward()
+    assert rel_err(out.float(), g["logits"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    _check_grads_vs_golden(m, g, tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_sap_adaptive_vs_reference(dtype, tol):
+    """SAP as train_sap_simple.py:231-250 builds it for adaptively patched input; encoder on the HIP kernels, the transposed-convolution
+    neck and the 1x1 header on torch / MIOpen"""
+    from UCF_VIT.simple.arch import SAP
+    g = load_golden("model_sap_adaptive.npz")
+    m = SAP(img_size=[64, 64], patch_size=8, in_chans=3, num_classes=3, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True,
+            fixed_length=16, sqrt_len=4, twoD=True, use_adaptive_pos_emb=True, sqrt_len_method=True, class_token=False, weight_init='skip')
+    m.load_state_dict(det_state_dict(m, 65, keep=()))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    out = m(g["x"].to(DEV), VARS, g["seq_ps"].to(DEV))
+    loss = torch.nn.MSELoss()(out.float(), g["target"].to(DEV))
+    loss.backward()
+    assert rel_err(out.float(), g["out"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    _check_grads_vs_golden(m, g, tol)
+
+
+def test_unetr_adaptive_sqrt_len_encoder_vs_oracle_and_trains():
+    """UNETR on adaptively patched 3-D input (basic_ct/unetr config: adaptive_patching, use_adaptive_pos_emb, single channel):
+    forward(x, variables, seq_ps, x_seq) with x_seq = the pseudo volume; encoder output and taps against the CPU oracle
+    (SqrtLenVIT, pinned by model_vit_sqrtlen_3d.npz), then a backward pass through the conv decoder (torch / MIOpen)"""
+    from oracle import ucf_vit_ref as R
+    from UCF_VIT.simple.arch import UNETR
+    from det_weights import det_tensor
+    kw = dict(img_size=[32, 32, 32], patch_size=4, in_chans=1, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False)
+    ref = R.SqrtLenVIT(kw["img_size"], patch_size=4, in_chans=1, num_classes=None, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False)
+    sd = det_state_dict(ref, 71, keep=())
+    ref.load_state_dict(sd)
+    m = UNETR(num_classes=3, linear_decoder=False, feature_size=4, skip_connection=True, adaptive_patching=True, fixed_length=8, sqrt_len=2,
+              use_adaptive_pos_emb=True, sqrt_len_method=True, **kw)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    m = m.to(DEV)
+    x_seq, sp = det_tensor((2, 1, 8, 8, 8), 72), torch.rand(2, 8, 4, generator=torch.Generator().manual_seed(3)) * 16
+    feats, taps = m.forward_intermediates(x_seq.to(DEV), VARS, sp.to(DEV), indices=m.skip_indices)
+    with torch.no_grad():
+        t = ref._pos_embed(ref.token_embeds(x_seq), sp)
+        want_taps = []
+        for i, blk in enumerate(ref.blocks):
+            t = blk(t)
+            if i in m.skip_indices:
+                want_taps.append(t)
+        want = ref.norm(t)
+    assert rel_err(feats.float().cpu(), want) < 1e-3
+    for a, b in zip(taps, want_taps):
+        assert rel_err(a.float().cpu(), b) < 1e-3
+    # the decoder needs grids of 16 x feat_size = img_size or an upsample: here 2 * 16 = 32 = img_size
+    out = m(det_tensor((2, 1, 32, 32, 32), 73).to(DEV), VARS, sp.to(DEV), x_seq.to(DEV))
+    assert tuple(out.shape) == (2, 3, 32, 32, 32)
+    out.float().square().mean().backward()
+    gsum = sum(float(p.grad.abs().sum()) for p in m.blocks.parameters())
+    assert math.isfinite(gsum) and gsum > 0 and m.adaptive_pos_dep_emb[0].weight.grad is not None
+
+
 def test_vit_adaptive_patching_trains_like_the_oracle():
     """10 AdamW steps on one adaptive batch (bf16 HIP path against the fp32 CPU oracle): same loss curve, loss goes down"""
     from oracle import ucf_vit_ref as R
@@ -220,10 +307,11 @@ def test_adamw_trajectory_vs_reference():
 
 
 def test_bf16_loss_curve_tracks_cpu_reference():
-    """BASELINE north_star: 'loss-curve-equivalent to the CPU reference'.  40 optimiser steps of the classification loop (reference
+    """BASELINE north_star: 'loss-curve-equivalent to the CPU reference' (50-100 steps, every loss within 2 % rel and the
+    same trend).  60 optimiser steps of the classification loop (reference
     order, train_class_simple.py:344-357) on a fixed cycle of 4 synthetic batches: the bf16 HIP path (fast-GELU epilogues, saved
     gelu', fused attention, grouped weight gradients, by-product bias gradients, fused AdamW) against the fp32 CPU oracle from the
-    same deterministic initialisation.  Tolerance: every loss within 4 % (+0.02 absolute) of the oracle's (measured: < 0.1 %),
+    same deterministic initialisation.  Tolerance: every loss within 2 % of the oracle's (measured: < 0.1 %),
     and both curves must go down (random labels: final loss below 97 % of the first)."""
     import sys
     import os
@@ -237,14 +325,14 @@ def test_bf16_loss_curve_tracks_cpu_reference():
     ref = R.VIT(kw["img_size"], patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=3, num_heads=2, sdpa=True)
     ref.load_state_dict(det_state_dict(ref, 77))
     opt = configure_optimizer(m, 2e-3, 0.9, 0.95, 1e-2)
-    sch = configure_scheduler(opt, 5, 40, 1e-5, 1e-6)
+    sch = configure_scheduler(opt, 5, 60, 1e-5, 1e-6)
     ropt = R.configure_optimizer(ref, 2e-3, 0.9, 0.95, 1e-2)
-    rsch = R.WarmupCosineLR(ropt, 5, 40, 1e-5, 1e-6)
+    rsch = R.WarmupCosineLR(ropt, 5, 60, 1e-5, 1e-6)
     gen = torch.Generator().manual_seed(123)
     xs = [torch.rand(16, 3, 32, 32, generator=gen) for _ in range(4)]
     ys = [torch.randint(0, 5, (16,), generator=gen) for _ in range(4)]
     got, want = [], []
-    for i in range(40):
+    for i in range(60):
         x, y = xs[i % 4], ys[i % 4]
         loss = cross_entropy_loss(m(x.to(DEV), VARS), y.to(DEV))
         loss.backward()
@@ -255,7 +343,7 @@ def test_bf16_loss_curve_tracks_cpu_reference():
         rl, _ = R.train_step_class(ref, ropt, rsch, x, y)
         want.append(rl.item())
     for i, (a, b) in enumerate(zip(got, want)):
-        assert abs(a - b) <= 0.04 * abs(b) + 0.02, (i, a, b)
+        assert abs(a - b) <= 0.02 * abs(b), (i, a, b)
     assert got[-1] < 0.97 * got[0] and want[-1] < 0.97 * want[0], (got[0], got[-1], want[0], want[-1])
 
 
@@ -472,6 +560,29 @@ def test_train_scripts_run_the_adaptive_patching_configuration(tmp_path):
     out = _run_entry("train_masked_simple.py", cfg, tmp_path, 29581)
     losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
     assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and losses[1] < losses[0], out
+
+
+def test_train_sap_and_unetr_scripts_run_adaptive_configs(tmp_path):
+    """basic_ct/sap and basic_ct/unetr set adaptive_patching + use_adaptive_pos_emb: SAP on 2-D pseudo images (fixed_length 16 = 3n+1
+    and a square), UNETR on 3-D pseudo volumes (fixed_length 8 = 7n+1 and a cube) with the full volume feeding the first conv encoder"""
+    cfg = _smoke_cfg()
+    a = cfg["model"]["net"]["init_args"]
+    a.update(tile_size=[64, 64], patch_size=8, embed_dim=96, depth=2, num_heads=3, adaptive_patching=True, fixed_length=16, use_adaptive_pos_emb=True)
+    cfg["data"]["num_classes"] = 3
+    cfg["data"]["batch_size"] = 4
+    cfg["model"]["lr"] = 1e-3
+    cfg["model"]["warmup_steps"] = 2
+    cfg["load_balancing"]["batches_per_rank_epoch"]["catsdogs"] = 6
+    out = _run_entry("train_sap_simple.py", cfg, tmp_path, 29582)
+    losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and losses[1] < losses[0], out
+    a.update(tile_size=[32, 32, 32], patch_size=4, twoD=False, fixed_length=8, feature_size=4, depth=4)
+    cfg["data"]["single_channel"] = True
+    cfg["data"]["batch_size"] = 2
+    cfg["load_balancing"]["batches_per_rank_epoch"]["catsdogs"] = 3
+    out = _run_entry("train_unetr_simple.py", cfg, tmp_path, 29583)
+    losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses), out
 
 
 def test_train_unetr_simple_entry_point_runs(tmp_path):

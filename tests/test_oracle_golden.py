@@ -136,6 +136,38 @@ def test_oracle_mae_adaptive_patching(name, adaptive_pos, seed):
             assert rel_err(p.grad, ref) < 2e-5, k
 
 
+def _check_grads(m, g):
+    for k, p in m.named_parameters():
+        ref = g["g." + k]
+        if p.grad is None:
+            assert float(ref.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, ref) < 2e-5, k
+
+
+def test_oracle_vit_sqrt_len_method_3d():
+    """adaptive patching as the UNETR / SAP scripts use it: pseudo-volume through the patch-embedding convolution + seq_ps positions"""
+    g = load_golden("model_vit_sqrtlen_3d.npz")
+    m = R.SqrtLenVIT([16, 16, 16], patch_size=4, in_chans=1, num_classes=5, embed_dim=96, depth=2, num_heads=3, class_token=False, twoD=False)
+    m.load_state_dict(det_state_dict(m, 62, keep=()))
+    out = m(g["x"], None, g["seq_ps"])
+    loss = torch.nn.CrossEntropyLoss()(out.flatten(0, 1), g["labels"])
+    loss.backward()
+    assert rel_err(out, g["logits"]) < 1e-5 and abs(loss.item() - g["loss"].item()) < 1e-6
+    _check_grads(m, g)
+
+
+def test_oracle_sap_adaptive():
+    g = load_golden("model_sap_adaptive.npz")
+    m = R.SAP([64, 64], patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2, twoD=True, sqrt_len=4, num_classes=3)
+    m.load_state_dict(det_state_dict(m, 65, keep=()))
+    out = m(g["x"], None, g["seq_ps"])
+    loss = torch.nn.MSELoss()(out, g["target"])
+    loss.backward()
+    assert rel_err(out, g["out"]) < 1e-5 and abs(loss.item() - g["loss"].item()) < 1e-6
+    _check_grads(m, g)
+
+
 def test_oracle_vit_tiny_config_T():
     """BASELINE configs[0]: ViT-Tiny/16, catsdogs tile 256x256, 2 classes (un-normalised 0..255 pixels)"""
     g = load_golden("model_vit_tiny_catsdogs.npz")

@@ -26,3 +26,24 @@ def seq_mse_loss(pred, seq, mask=None):
 
 def cross_entropy_loss(logits, labels):
     return HF.cross_entropy(logits, labels)
+
+
+class DiceBLoss(torch.nn.Module):
+    """Dice + binary cross-entropy over the non-background channels of a segmentation map (reference utils/metrics.py:95-121, the
+    loss of train_sap_simple.py:44-46): sigmoid, channels 1.. flattened, loss = w * BCE + (1 - w) * (1 - dice).  Loss arithmetic on
+    the [B, classes, ...] output map runs on torch ops in fp32 (outside the token path)."""
+
+    def __init__(self, weight=0.5, num_class=2, size_average=True):
+        super().__init__()
+        self.weight, self.num_class = weight, num_class
+
+    def forward(self, inputs, targets, smooth=1, act=True):
+        inputs = inputs.float()
+        if act:
+            inputs = torch.sigmoid(inputs)
+        pred = torch.flatten(inputs[:, 1:])
+        true = torch.flatten(targets[:, 1:].float())
+        inter = (pred * true).sum()
+        dice_loss = 1 - (2. * inter + smooth) / (pred.sum() + true.sum() + smooth)
+        bce = torch.nn.functional.binary_cross_entropy(pred, true, reduction='mean')
+        return self.weight * bce + (1 - self.weight) * dice_loss

@@ -72,6 +72,29 @@ class SyntheticLoader:
             yield data.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
 
 
+def sqrt_len_of(fixed_length, twoD):
+    """side of the token grid the reference's UNETR / SAP scripts reshape an adaptive sequence into (train_unetr_simple.py:202-220)"""
+    if twoD:
+        s = int(round(fixed_length ** 0.5))
+        assert s * s == fixed_length, "sqrt of fixed length needs to be a whole number"
+        assert fixed_length % 3 == 1, "Quadtree fixed length needs to be 3n+1, where n is some integer"
+    else:
+        s = int(round(fixed_length ** (1.0 / 3.0)))
+        assert s ** 3 == fixed_length, "cube root of fixed length needs to be a whole number"
+        assert fixed_length % 7 == 1, "Octtree fixed length needs to be 7n+1, where n is some integer"
+    return s
+
+
+def seq_to_pseudo_image(seq, sqrt_len, patch_size, twoD):
+    """[B, C, S, P] -> [B, C, (s1 p1), (s2 p2)[, (s3 p3)]] as train_unetr_simple.py:43-47 does with einops"""
+    import einops
+    if twoD:
+        return einops.rearrange(seq, 'b c (s1 s2) (ps1 ps2) -> b c (s1 ps1) (s2 ps2)', s1=sqrt_len, s2=sqrt_len, ps1=patch_size,
+                                ps2=patch_size).contiguous()
+    return einops.rearrange(seq, 'b c (s1 s2 s3) (ps1 ps2 ps3) -> b c (s1 ps1) (s2 ps2) (s3 ps3)', s1=sqrt_len, s2=sqrt_len, s3=sqrt_len,
+                            ps1=patch_size, ps2=patch_size, ps3=patch_size).contiguous()
+
+
 class SyntheticSeqLoader:
     """per-rank synthetic batches shaped like the reference's adaptive-patching dataloader output (train_class_simple.py:322-337):
     seq fp32 [B, C, S, P] (S = fixed_length resized patches of P = p^nd pixels), seq_ps fp32 [B, S, 3|4] = (size, position...),

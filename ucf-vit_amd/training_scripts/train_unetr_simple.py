@@ -7,8 +7,8 @@ import sys
 import torch
 import torch.nn.functional as F
 
-from _common import (SyntheticLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
-                     save_checkpoint)
+from _common import (SyntheticLoader, SyntheticSeqLoader, StepTimer, init_distributed, iters_per_epoch, load_config, maybe_resume, model_args,
+                     save_checkpoint, seq_to_pseudo_image, sqrt_len_of)
 from UCF_VIT.simple.arch import UNETR
 from UCF_VIT.utils.fused_attn import FusedAttn
 from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
@@ -32,15 +32,21 @@ def training_step(data, variables, label, net):
     return dice_ce_loss(output, label), output
 
 
+def training_step_adaptive(data, seq, label, variables, net, patch_size, twoD, seq_ps, sqrt_len):
+    """reference :43-52: the full-resolution volume feeds the first conv encoder, the token sequence (as a pseudo volume) the ViT"""
+    output = net(data, variables, seq_ps, seq_to_pseudo_image(seq, sqrt_len, patch_size, twoD))
+    return dice_ce_loss(output, label), output
+
+
 def main(device, local_rank, rank, world):
     conf = load_config(sys.argv[1])
     margs, a, d = model_args(conf)
-    if margs["adaptive_patching"]:
-        raise NotImplementedError("UNETR on adaptively patched input (x_seq + sqrt_len grids) is a 'next' row (SURVEY.md §8f); set adaptive_patching False")
+    adaptive = margs["adaptive_patching"]
+    sqrt_len = sqrt_len_of(margs["fixed_length"], margs["twoD"]) if adaptive else None
     m = conf["model"]
     model = UNETR(num_classes=d["num_classes"], class_token=False, weight_init='', linear_decoder=a.get("linear_decoder", False),
-                  feature_size=a.get("feature_size", 16), skip_connection=a.get("skip_connection", True),
-                  FusedAttn_option=FusedAttn.HIP, **margs).to(device)
+                  feature_size=a.get("feature_size", 16), skip_connection=a.get("skip_connection", True), sqrt_len=sqrt_len,
+                  sqrt_len_method=adaptive, FusedAttn_option=FusedAttn.HIP, **margs).to(device)
     model.set_compute_dtype(torch.bfloat16 if conf["trainer"].get("data_type", "float32") == "bfloat16" else torch.float32)
     net = HipDataParallel(model)
     optimizer = configure_optimizer(model, float(m["lr"]), float(m["beta_1"]), float(m["beta_2"]), float(m["weight_decay"]))   # PyYAML reads "1e-5" as str
@@ -49,12 +55,19 @@ def main(device, local_rank, rank, world):
     variables = d["dict_in_variables"][d["dataset"]]
     loader = SyntheticLoader(d["batch_size"], margs["in_chans"], margs["img_size"], d["num_classes"], iters_per_epoch(conf), device,
                              1234 + rank, volumetric_labels=True)
+    seq_loader = SyntheticSeqLoader(d["batch_size"], margs["in_chans"], margs["img_size"], margs["patch_size"], margs["fixed_length"], 0,
+                                    iters_per_epoch(conf), device, 4321 + rank) if adaptive else None
     for epoch in range(epoch_start, conf["trainer"]["max_epochs"]):
         model.train()
         epoch_loss = torch.zeros((), device=device)
         timer = StepTimer()
+        seqs = iter(seq_loader) if adaptive else None
         for data, label in loader:
-            loss, _ = training_step(data / 255.0, variables, label, net)       # basic_ct volumes are min-max normalised
+            if adaptive:
+                seq, seq_ps, _ = next(seqs)
+                loss, _ = training_step_adaptive(data / 255.0, seq / 255.0, label, variables, net, margs["patch_size"], margs["twoD"], seq_ps, sqrt_len)
+            else:
+                loss, _ = training_step(data / 255.0, variables, label, net)       # basic_ct volumes are min-max normalised
             epoch_loss += loss.detach()
             loss.backward()
             optimizer.step()
