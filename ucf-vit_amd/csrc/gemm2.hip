@@ -374,6 +374,273 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
 }
 
 // =====================================================================================================================
+// ONE WAVE PER SIMD variant of the persistent 256x256x64 kernel: 4 waves (2 x 2), 128x128 output per wave, the 256 accumulator
+// registers in AGPRs.  A wave reads 16 fragments per 64 MFMAs (the 8-wave kernels read 12 per 32): a third fewer LDS bytes per MFMA.
+// With one wave per SIMD nothing else hides a fragment read, so the wave pipelines itself: the fragments of half-step (kt, c ^ 1)
+// are read into a second register set while the 64 MFMAs of (kt, c) issue.  LDS-DMA runs two K-tiles ahead; the one barrier per
+// K-tile sits at its midpoint, where every wave has finished READING K-tile kt (its second half is in registers) and its own DMA
+// pieces of K-tile kt+1 have landed: after it, K-tile kt+2 is issued into kt's buffer and kt+1 may be read.
+//   K-tile kt:  [ MFMA(kt,c0) || reads(kt,c1) ] -> lgkmcnt(0), vmcnt(0), barrier, DMA(kt+2) -> [ MFMA(kt,c1) || reads(kt+1,c0) ]
+// The epilogue stages through its own 17-KiB LDS region (both pipeline buffers are busy at a tile boundary).  KC x KC operands only.
+// =====================================================================================================================
+template <typename OutT>
+__device__ __forceinline__ void epi4_row8(float* v, int m, int n, OutT* __restrict__ C, const Epi2& ep) {
+    if (ep.act == UCFVIT_ACT_GELU) {
+        if (ep.aux_out) {
+            Vec16<bf16> o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+            *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = o.get(r);
+        }
+        gelu_fast8(v);
+    } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
+        const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+        float hf[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
+        gelu_grad_fast8(v, hf);
+    } else if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV) {
+        float df[8];
+        gelu_and_grad_fast8(v, df);
+        Vec16<bf16> o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o.set(r, df[r]);
+        *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+    } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
+        const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= h.get(r);
+    }
+    if (ep.residual) {
+        const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
+    }
+    OutT* cp = C + (int64_t)m * ep.ldc + n;
+    if constexpr (sizeof(OutT) == 2) {
+        if (ep.accumulate) {
+            const Vec16<bf16> old = *reinterpret_cast<const Vec16<bf16>*>(cp);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += old.get(r);
+        }
+        Vec16<bf16> o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o.set(r, v[r]);
+        *reinterpret_cast<Vec16<bf16>*>(cp) = o;
+    } else {
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        if (ep.accumulate) {
+            o0 += *reinterpret_cast<const f32x4*>(cp);
+            o1 += *reinterpret_cast<const f32x4*>(cp + 4);
+        }
+        *reinterpret_cast<f32x4*>(cp) = o0;
+        *reinterpret_cast<f32x4*>(cp + 4) = o1;
+    }
+}
+
+constexpr int G4_STAGE_OFF = 2 * (256 + 256) * 128;            // after the two pipeline buffers
+constexpr int G4_PADW = 64 + 4;                                // staged row: 64 fp32 columns + pad
+constexpr int G4_SMEM = G4_STAGE_OFF + 4 * 16 * G4_PADW * 4;   // 148480 bytes
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C, int M, int N,
+                                                    int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m, int tiles_n) {
+    constexpr int KC = UCFVIT_LAYOUT_KC;
+    constexpr int BM = 256, BN = 256, FM = 8, FN = 8;
+    constexpr int A_BYTES = BM * 128, BUF = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
+    const int g = lane >> 4, li = lane & 15;
+    const int tiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
+    const int nk = (K + BK2 - 1) / BK2;
+    const int klast = K - (nk - 1) * BK2;
+
+    // position in the flat sequence of (output tile, K-tile) pairs of this workgroup
+    auto tile_at = [&](int round, int& m0, int& n0) -> bool {
+        const int base = round * G;
+        if (base >= tiles) return false;
+        const int cnt = min(G, tiles - base);
+        if (bid >= cnt) return false;
+        tile_origin(base + xcd_remap(bid, cnt), tiles_m, tiles_n, BM, BN, m0, n0);
+        return true;
+    };
+    int c_round = 0, c_m0 = 0, c_n0 = 0;                  // compute cursor (output tile)
+    if (!tile_at(0, c_m0, c_n0)) return;
+    int p_round = 0, p_kt = 0, p_m0 = c_m0, p_n0 = c_n0;  // prefetch cursor
+    bool p_valid = true;
+    int pf_it = 0;                                        // running index of the K-tile the prefetch cursor points at
+    // per-lane byte offsets of this wave's 8 + 8 DMA pieces inside the prefetch cursor's output tile (rows clamped at the matrix edge);
+    // the K position is a wave-uniform offset added at issue time, so one issue = one 64-bit add + the DMA instruction
+    unsigned poffA[8], poffB[8];
+    auto piece_offsets = [&](unsigned (&off)[8], int64_t ld, int r0, int R) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (wave * 8 + i) * 8 + (lane >> 3);
+            const int gslot = (lane & 7) ^ (row & 7);
+            int gr = r0 + row;
+            gr = gr < R ? gr : R - 1;
+            off[i] = (unsigned)(((int64_t)gr * ld + gslot * 8) * 2);
+        }
+    };
+    piece_offsets(poffA, lda, p_m0, M);
+    piece_offsets(poffB, ldb, p_n0, N);
+    auto prefetch = [&]() {
+        if (!p_valid) return;
+        char* dst = smem + (pf_it & 1) * BUF;
+        if (p_kt == nk - 1 && klast < BK2) {              // ragged last K-tile: lanes past K read the zero page
+            issue_tile<KC, BM, 4>(A, lda, p_m0, p_kt * BK2, M, dst, wave, lane, klast);
+            issue_tile<KC, BN, 4>(B, ldb, p_n0, p_kt * BK2, N, dst + A_BYTES, wave, lane, klast);
+        } else {
+            const char* ak = reinterpret_cast<const char*>(A) + (int64_t)p_kt * (BK2 * 2);
+            const char* bk = reinterpret_cast<const char*>(B) + (int64_t)p_kt * (BK2 * 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ak + poffA[i]), (lptr_t)(dst + (wave * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(bk + poffB[i]), (lptr_t)(dst + A_BYTES + (wave * 8 + i) * 1024), 16, 0, 0);
+        }
+        ++pf_it;
+        if (++p_kt == nk) {
+            p_kt = 0;
+            ++p_round;
+            p_valid = tile_at(p_round, p_m0, p_n0);
+            if (p_valid) {
+                piece_offsets(poffA, lda, p_m0, M);
+                piece_offsets(poffB, ldb, p_n0, N);
+            }
+        }
+    };
+    prefetch();
+    prefetch();
+
+    bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+#define G4_READ(fa_, fb_, buf_, c_)                                                            \
+    do {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) fb_[j] = load_frag2<KC, BN>((buf_) + A_BYTES, wn + 16 * j, c_, lane); \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) fa_[i] = load_frag2<KC, BM>((buf_), wm + 16 * i, c_, lane);          \
+    } while (0)
+// The MFMAs are inline asm with the accumulator tied in place in an AGPR ("+a"): with all 256 AGPRs holding accumulators hipcc's
+// allocator otherwise un-ties destination and addend of most MFMAs and copies 4 AGPRs in front of each (measured: 2x slower loop).
+#define G4_MFMA_ROWS(fa_, fb_, I0_, I1_)                                                       \
+    do {                                                                                       \
+        _Pragma("unroll") for (int i = I0_; i < I1_; ++i)                                      \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb_[j]), "v"(fa_[i])); \
+    } while (0)
+#define G4_MFMA(fa_, fb_)                                                                      \
+    do {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb_[j]), "v"(fa_[i])); \
+    } while (0)
+
+    // the first K-tile: wait for it (the second one, 16 wave-instructions, may stay in flight), make it visible, read its first half
+    if (nk > 1 || p_valid || p_round > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int it = 0;
+    G4_READ(fa0, fb0, smem, 0);      // (hipcc places the lgkmcnt waits of the fragment sets itself, counted, in front of their first MFMA)
+
+    for (;;) {
+        const int m0 = c_m0, n0 = c_n0;
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // is there an output tile after this one?
+        int n_m0 = 0, n_n0 = 0;
+        const bool has_next = tile_at(c_round + 1, n_m0, n_n0);
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const char* buf = smem + (it & 1) * BUF;
+            const char* nbuf = smem + ((it + 1) & 1) * BUF;
+            // (hipcc drains lgkmcnt in front of the first asm MFMA that uses a loaded register: start on set 0 first, then issue the
+            // reads of the second half of this K-tile into set 1, so that drain only meets reads that completed long ago)
+            G4_MFMA_ROWS(fa0, fb0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            G4_READ(fa1, fb1, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            G4_MFMA_ROWS(fa0, fb0, 1, FM);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my reads of `buf` are done; my pieces of K-tile it+1 have landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch();                                   // K-tile it+2 -> `buf`
+            const bool more = (kt + 1 < nk) || has_next;
+            G4_MFMA_ROWS(fa1, fb1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) G4_READ(fa0, fb0, nbuf, 0);         // first half of the next K-tile (possibly of the next output tile)
+            __builtin_amdgcn_sched_barrier(0);
+            G4_MFMA_ROWS(fa1, fb1, 1, FM);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // the asm MFMAs are opaque to the hazard recogniser: let the last results retire before the accumulators are read
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        // ---- epilogue: 16-row strips of the wave's 128x128 block, each as two 64-column halves through a wave-private staging strip.
+        // The strip loop is a real loop (one copy of the row code); the accumulators keep compile-time indices through the switch.
+        float* stage = reinterpret_cast<float*>(smem + G4_STAGE_OFF) + wave * (16 * G4_PADW);
+        const int prow = lane >> 3, pcol = (lane & 7) * 8;
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < FM; ++i) {
+            f32x4 row[FN];
+#define G4_TAKE(I_) _Pragma("unroll") for (int j = 0; j < FN; ++j) row[j] = acc[I_][j]
+            switch (i) {
+                case 0: G4_TAKE(0); break;
+                case 1: G4_TAKE(1); break;
+                case 2: G4_TAKE(2); break;
+                case 3: G4_TAKE(3); break;
+                case 4: G4_TAKE(4); break;
+                case 5: G4_TAKE(5); break;
+                case 6: G4_TAKE(6); break;
+                default: G4_TAKE(7); break;
+            }
+#undef G4_TAKE
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    f32x4 v = row[4 * h + jj];
+                    const int n = n0 + wn + 16 * (4 * h + jj) + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= ep.alpha;
+                    if (ep.bias && n < N) {
+                        const Vec4<bf16> b = *reinterpret_cast<const Vec4<bf16>*>(ep.bias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += b.get(r);
+                    }
+                    *reinterpret_cast<f32x4*>(stage + li * G4_PADW + 16 * jj + 4 * g) = v;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 16; rr += 8) {
+                    const int rw = rr + prow;
+                    const int m = m0 + wm + 16 * i + rw;
+                    const int n = n0 + wn + 64 * h + pcol;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + rw * G4_PADW + pcol);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + rw * G4_PADW + pcol + 4);
+                    if (m >= M || n >= N) continue;
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    epi4_row8<OutT>(v, m, n, C, ep);
+                }
+            }
+        }
+        if (!has_next) break;
+        ++c_round;
+        c_m0 = n_m0;
+        c_n0 = n_n0;
+    }
+#undef G4_READ
+#undef G4_MFMA
+#undef G4_MFMA_ROWS
+}
+
+// =====================================================================================================================
 // PING-PONG variant of the persistent 256x256x64 kernel (8 waves).  The two wave groups G0 = waves 0-3 (rows 0-127 of the
 // tile) and G1 = waves 4-7 (rows 128-255) — wave w and w+4 share a SIMD — run the SAME program skewed by one barrier
 // interval: while one group is in a MEM interval (DMA issue for the next K-tile + ds_read of a 32-deep fragment set), the
@@ -1164,10 +1431,44 @@ static bool pp_enabled() {
     return flag == 1;
 }
 
+template <typename OutT>
+int launch4(const ucfvit_gemm_desc* d, Epi2 ep, hipStream_t s) {
+    const int tiles_m = (int)((d->M + 255) / 256), tiles_n = (int)((d->N + 255) / 256);
+    auto kern = gemm4_kernel<OutT>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
+        if (e != hipSuccess) {
+            ucfvit_set_error("ucfvit_gemm: cannot raise dynamic LDS to %d bytes: %s", G4_SMEM, hipGetErrorString(e));
+            return UCFVIT_ERR_HIP;
+        }
+        done = true;
+    }
+    const int tiles = tiles_m * tiles_n;
+    const int gx = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), G4_SMEM, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C, (int)d->M, (int)d->N,
+                       (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n);
+    UCF_LAUNCH_CHECK("ucfvit_gemm(v4 one wave per SIMD)");
+    return UCFVIT_OK;
+}
+
+static bool w4_enabled() {
+    static int flag = -1;
+    if (flag < 0) {
+        const char* e = getenv("UCFVIT_GEMM_W4");
+        flag = (e && e[0] == '1') ? 1 : 0;
+    }
+    return flag == 1;
+}
+
 template <int LA, int LB, typename OutT>
 int dispatch_tile(const ucfvit_gemm_desc* d, const Plan2& p, const Epi2& ep, hipStream_t s) {
     const int64_t a_bytes = ((d->a_layout == UCFVIT_LAYOUT_KC ? d->M : d->K) * d->lda) * 2;
     const int64_t b_bytes = ((d->b_layout == UCFVIT_LAYOUT_KC ? d->N : d->K) * d->ldb) * 2;
+    if constexpr (LA == UCFVIT_LAYOUT_KC && LB == UCFVIT_LAYOUT_KC) {
+        if (p.big && w4_enabled() && p.splits == 1 && !ep.slab && !ep.cs_partial && d->K >= 2 * BK2 && a_bytes < (1ll << 32) && b_bytes < (1ll << 32))
+            return launch4<OutT>(d, ep, s);
+    }
     if (p.big && pp_enabled() && a_bytes < (1ll << 32) && b_bytes < (1ll << 32)) return launch3<LA, LB, OutT>(d, p, ep, s);
     if (p.big) return launch2<LA, LB, 256, 256, 2, 4, OutT>(d, p, ep, s);
     return launch2<LA, LB, 128, 128, 2, 2, OutT>(d, p, ep, s);
