@@ -44,7 +44,7 @@ int ucfvit_abi_version(void);
 const char* ucfvit_last_error(void);
 
 /* Diagnostic (no reference counterpart): launches a pure bf16 MFMA stream (operands in registers, 2 waves per SIMD on every CU,
- * `iters` x 8 v_mfma_f32_16x16x32_bf16 per wave) and returns the FLOPs it executes (< 0: error).  Timed with HIP events by
+ * `iters` x 16 v_mfma_f32_16x16x32_bf16 per wave on 16 independent accumulators) and returns the FLOPs it executes (< 0: error).  Timed with HIP events by
  * bench.py: the rate is the ceiling the chip's clock / power management leaves to any bf16 MFMA kernel on that device.
  * sink: >= 256 floats of device memory (never written in practice). */
 int64_t ucfvit_mfma_probe(float* sink, int iters, void* stream);

@@ -53,7 +53,7 @@ def workspace(nbytes, device):
     return ws
 
 
-def mfma_probe(iters=20000):
+def mfma_probe(iters=10000):
     """diagnostic: one launch of a pure bf16 MFMA stream on the current stream; returns the FLOPs it executes"""
     L = _l.load()
     sink = workspace(1024, torch.device("cuda", torch.cuda.current_device()))

@@ -16,9 +16,11 @@ extern "C" int ucfvit_abi_version(void) { return UCFVIT_ABI_VERSION; }
 extern "C" const char* ucfvit_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------------
-// Diagnostic: a pure v_mfma_f32_16x16x32_bf16 stream (operands in registers, no memory traffic), 2 waves per SIMD on every CU.
-// Its rate is the ceiling the chip's power management leaves to ANY bf16 MFMA kernel on the box at hand (the clock falls under
-// matrix load: MI355X_MICROARCH.md "DVFS give-back"); bench.py reports it next to the nominal 2.5 PFLOP/s.
+// Diagnostic: a pure v_mfma_f32_16x16x32_bf16 stream (operands in registers, no memory traffic), 2 waves per SIMD on every CU,
+// 16 independent accumulators per wave and 32 MFMAs per loop trip (with 8 accumulators and 8 MFMAs per trip the same loop reports
+// only 1.25-1.3 PFLOP/s: the taken branch and the accumulate dependency show; tools/mfma_peak.hip has the whole matrix).
+// Its rate is what the matrix pipes deliver at the clock the chip holds under a dense MFMA stream; bench.py reports it next to
+// the nominal 2.5 PFLOP/s.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void mfma_probe_kernel(float* __restrict__ sink, int iters) {
@@ -28,16 +30,18 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(float* __restrict__ sin
         a[e] = (bf16)(0.37f * (float)((threadIdx.x * 7 + e * 3) % 13) - 2.f);
         b[e] = (bf16)(0.21f * (float)((threadIdx.x * 5 + e * 11) % 17) - 1.7f);
     }
-    f32x4 acc[8];
+    f32x4 acc[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < iters; ++it) {
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it += 2) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678f) sink[threadIdx.x] = s;     // keeps the loop alive; practically never true
 }
 }  // namespace
@@ -50,5 +54,5 @@ extern "C" int64_t ucfvit_mfma_probe(float* sink, int iters, void* stream) {
     const int grid = 512;                            // 2 workgroups of 4 waves per CU
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sink, iters);
     UCF_LAUNCH_CHECK("ucfvit_mfma_probe");
-    return (int64_t)grid * 4 * iters * 8 * (2ll * 16 * 16 * 32);
+    return (int64_t)grid * 4 * ((iters + 1) / 2 * 2) * 16 * (2ll * 16 * 16 * 32);
 }
