@@ -598,3 +598,20 @@ def test_train_unetr_simple_entry_point_runs(tmp_path):
     out = _run_entry("train_unetr_simple.py", cfg, tmp_path, 29579)
     losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
     assert len(losses) == 2 and all(math.isfinite(v) for v in losses), out
+
+
+def test_empty_batch_forward_returns_empty_logits():
+    """edge case: a batch of zero images goes through every forward kernel entry point (im2col, GEMMs, LayerNorm, attention,
+    token assembly, adaptive front end) without a launch and yields [0, classes] like the torch reference does"""
+    from UCF_VIT.simple.arch import VIT
+    for dtype in (torch.float32, torch.bfloat16):
+        m = build(VIT, VIT_KW, 21, dtype).eval()
+        with torch.no_grad():
+            out = m(torch.empty(0, 3, 32, 32, device=DEV), VARS)
+        assert tuple(out.shape) == (0, 5) and out.dtype == dtype
+        ma = VIT(num_classes=5, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True, fixed_length=12, img_size=[32, 32], patch_size=8,
+                 in_chans=3, use_adaptive_pos_emb=True).to(DEV).eval()
+        ma.set_compute_dtype(dtype)
+        with torch.no_grad():
+            out = ma(torch.empty(0, 3, 12, 64, device=DEV), VARS, torch.empty(0, 12, 3, device=DEV))
+        assert tuple(out.shape) == (0, 5)

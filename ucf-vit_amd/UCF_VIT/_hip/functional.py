@@ -483,7 +483,10 @@ class PatchEmbedFn(torch.autograd.Function):
         ctx.save_for_backward(cols, weight, bias)
         ctx.cdtype = cdtype
         B = img.shape[0]
-        return y.view(B, -1, w.shape[0])
+        L = 1
+        for d_ in img.shape[2:]:
+            L *= d_ // patch
+        return y.view(B, L, w.shape[0])          # (explicit L: an empty batch has no elements to infer it from)
 
     @staticmethod
     def backward(ctx, dy):

@@ -308,6 +308,7 @@ inline PosPlan pos_plan(int64_t rows, int64_t D, int epv, int rows_per_lane) {
 }  // namespace
 
 extern "C" int ucfvit_seq_patches(const float* x, void* rows_out, int64_t B, int64_t C, int64_t S, int64_t P, int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;                      // empty batch (pointers may be NULL)
     UCF_CHECK_ARG(x && rows_out, "ucfvit_seq_patches: null pointer");
     UCF_CHECK_ARG(DTYPE_OK(dtype), "ucfvit_seq_patches: bad dtype %d", dtype);
     UCF_CHECK_ARG(B >= 0 && C > 0 && S > 0 && P > 0, "ucfvit_seq_patches: bad shape B=%lld C=%lld S=%lld P=%lld", (long long)B, (long long)C,
@@ -330,6 +331,7 @@ extern "C" int ucfvit_seq_patches(const float* x, void* rows_out, int64_t B, int
 
 extern "C" int ucfvit_adaptive_pos_fwd(const void* x, const float* seq_ps, const void* w, const void* bias, const void* cls, void* out,
                                        int64_t B, int64_t S, int64_t D, int kin, int has_cls, int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;                      // empty batch (pointers may be NULL)
     UCF_CHECK_ARG(x && seq_ps && w && bias && out, "ucfvit_adaptive_pos_fwd: null pointer");
     UCF_CHECK_ARG(!has_cls || cls, "ucfvit_adaptive_pos_fwd: has_cls without cls pointer");
     UCF_CHECK_ARG(DTYPE_OK(dtype), "ucfvit_adaptive_pos_fwd: bad dtype %d", dtype);

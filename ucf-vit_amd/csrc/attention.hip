@@ -551,6 +551,7 @@ int check_attn_args(const char* name, int64_t B, int64_t N, int64_t H, int64_t d
 
 extern "C" int ucfvit_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh, float scale,
                                     int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;                      // empty batch (pointers may be NULL)
     UCF_CHECK_ARG(qkv && out && lse, "ucfvit_attention_fwd: null pointer");
     int rc = check_attn_args("ucfvit_attention_fwd", B, N, H, dh, dtype);
     if (rc) return rc;

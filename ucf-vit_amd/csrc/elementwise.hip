@@ -471,6 +471,7 @@ inline unsigned ew_grid(int64_t work_items, int block = 256) {
 // ---------------------------------------------------------------------------------------------------
 extern "C" int ucfvit_im2col(const float* img, void* cols, int64_t B, int64_t C, const int64_t* dims, int nd, int64_t p, int dtype,
                              void* stream) {
+    if (B == 0) return UCFVIT_OK;                      // empty batch (pointers may be NULL)
     UCF_CHECK_ARG(img && cols && dims, "ucfvit_im2col: null pointer");
     UCF_CHECK_ARG(nd == 2 || nd == 3, "ucfvit_im2col: nd must be 2 or 3");
     UCF_CHECK_ARG(DTYPE_OK(dtype), "ucfvit_im2col: bad dtype %d", dtype);
@@ -496,6 +497,7 @@ extern "C" int ucfvit_im2col(const float* img, void* cols, int64_t B, int64_t C,
 
 extern "C" int ucfvit_tokens_fwd(const void* patches, const void* cls, const void* pos, void* out, int64_t B, int64_t L, int64_t D,
                                  int has_cls, int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;                      // empty batch (pointers may be NULL)
     UCF_CHECK_ARG(patches && out, "ucfvit_tokens_fwd: null pointer");
     UCF_CHECK_ARG(!has_cls || cls, "ucfvit_tokens_fwd: has_cls without cls pointer");
     UCF_CHECK_ARG(DTYPE_OK(dtype), "ucfvit_tokens_fwd: bad dtype %d", dtype);

@@ -363,6 +363,7 @@ static bool v2_enabled() {
 
 extern "C" int ucfvit_gemm(const ucfvit_gemm_desc* d, void* stream) {
     UCF_CHECK_ARG(d != nullptr, "ucfvit_gemm: null descriptor");
+    if (d->M == 0 || d->N == 0) return UCFVIT_OK;      // empty batch / empty output: nothing to write (pointers may be NULL)
     UCF_CHECK_ARG(d->A && d->B && d->C, "ucfvit_gemm: null operand pointer");
     UCF_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "ucfvit_gemm: negative size");
     UCF_CHECK_ARG(d->a_layout == 0 || d->a_layout == 1, "ucfvit_gemm: bad a_layout %d", d->a_layout);

@@ -341,6 +341,7 @@ int ln_bwd_t(const void* dy, const void* x, const void* gamma, const float* mean
 
 extern "C" int ucfvit_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                     int64_t rows, int64_t D, float eps, int dtype, void* stream) {
+    if (rows == 0) return UCFVIT_OK;                   // empty batch (pointers may be NULL)
     UCF_CHECK_ARG(x && gamma && beta && y && mean && rstd, "ucfvit_layernorm_fwd: null pointer");
     UCF_CHECK_ARG(rows >= 0 && D > 0, "ucfvit_layernorm_fwd: bad shape rows=%lld D=%lld", (long long)rows, (long long)D);
     UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(y) && ucf_is_aligned16(gamma) && ucf_is_aligned16(beta),
