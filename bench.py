@@ -161,11 +161,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switches (never set by the driver): UCFVIT_BENCH_BACKEND=gloo + UCFVIT_BENCH_ONE_GPU=1 run the N > 1 code path with
+    # every rank on GPU 0 and host-staged gradient reduction, because RCCL refuses two ranks on one device (1-GPU development box).
+    backend = os.environ.get("UCFVIT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("UCFVIT_BENCH_ONE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from UCF_VIT.simple.arch import VIT
     from UCF_VIT.utils.fused_attn import FusedAttn
@@ -240,7 +247,7 @@ def main():
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     final_loss = float(loss.item())
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -275,7 +282,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} train step (fwd+bwd+AdamW), synthetic U{{0..255}} images resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
-                       "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, RCCL, overlapped with backward") if world > 1 else "none (1 rank)"},
+                       "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, " + ("RCCL" if backend == "nccl" else backend + " (rehearsal)") + ", overlapped with backward") if world > 1 else "none (1 rank)"},
             "roofline": {"bound": "mfma", "kernel": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
                                              "weight-gradient launch of the timed region)" % args.dtype,
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
