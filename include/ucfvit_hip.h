@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 5
+#define UCFVIT_ABI_VERSION 6
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -186,6 +186,23 @@ int64_t ucfvit_adaptive_pos_bwd_workspace(int64_t B, int64_t S, int64_t D, int k
 int ucfvit_adaptive_pos_bwd(const void* dout, const float* seq_ps, const void* w, const void* bias, void* dx, float* dw, float* dbias,
                             float* dcls, int64_t B, int64_t S, int64_t D, int kin, int has_cls, int accumulate, void* workspace,
                             int dtype, void* stream);
+
+/* GPU-side fixed-length quadtree patcher (the adaptive-patching data transform: dataloaders/quadtree.py:84-174 FixedQuadTree,
+ * dataloaders/transform.py:9-55 Patchify), a whole batch per call.  Edge detection is not included: `edges` is its result.
+ * ucfvit_quadtree_build: edges uint8 [B][H][W] (cv2.Canny output: 0 / 255).  Per image the reference's greedy refinement: replace
+ *     the FIRST node of maximum value (value = sum(region) / 255) by its quadrants lt, rt, lb, rb in place until fixed_length = L
+ *     nodes exist (L must be 3n+1, train_unetr_simple.py:214) or that node is 2 pixels wide.  Bit-exact integer logic.
+ *     nodes int32 [B][L][4] = (x1, x2, y1, y2) in list order, values int32 [B][L], count int32 [B] (valid nodes; the rest is padding),
+ *     seq_ps fp32 [B][L][3] = (size = x2-x1, centre x, centre y); padding: size 0, centre (-1, -1) like FixedQuadTree.serialize.
+ *     workspace: ucfvit_quadtree_workspace bytes (summed-area tables).  H, W < 32768, H*W*255 < 2^32.
+ * ucfvit_quadtree_serialize: img fp32 [B][H][W][C] (channels last, as the reference's numpy images); every node's region resampled
+ *     to p x p with the cv2.INTER_CUBIC kernel (A = -0.75, aligned pixel centres, replicated border) into seq fp32 [B][L][p][p][C];
+ *     Patchify's plain reshape of that memory to [C][L][p*p] per image is the model input x[B][C][S][P].  Padding nodes: zeros. */
+int64_t ucfvit_quadtree_workspace(int64_t B, int64_t H, int64_t W);
+int ucfvit_quadtree_build(const uint8_t* edges, int32_t* nodes, int32_t* values, int32_t* count, float* seq_ps, int64_t B, int64_t H,
+                          int64_t W, int64_t L, void* workspace, void* stream);
+int ucfvit_quadtree_serialize(const float* img, const int32_t* nodes, const int32_t* count, float* seq, int64_t B, int64_t H, int64_t W,
+                              int64_t C, int64_t L, int64_t p, void* stream);
 
 /* Softmax cross-entropy, mean over the batch (nn.CrossEntropyLoss, training_scripts/train_class_simple.py:24-30).
  * logits [B][C] dtype, labels int64 [B]; loss: fp32 scalar (device); row_loss: fp32 [B] per-sample losses (also scratch);

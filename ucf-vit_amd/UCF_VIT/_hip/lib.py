@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
@@ -54,6 +54,9 @@ SIGNATURES = {
     "ucfvit_tokens_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P]),
     "ucfvit_tokens_bwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
     "ucfvit_seq_patches": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "ucfvit_quadtree_workspace": (_I64, [_I64, _I64, _I64]),
+    "ucfvit_quadtree_build": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "ucfvit_quadtree_serialize": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "ucfvit_adaptive_pos_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
     "ucfvit_adaptive_pos_bwd_workspace": (_I64, [_I64, _I64, _I64, _I, _I, _I]),
     "ucfvit_adaptive_pos_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _I, _P]),

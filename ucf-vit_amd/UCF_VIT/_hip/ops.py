@@ -349,6 +349,41 @@ def adaptive_pos_bwd(dout, seq_ps, w, bias, B, S, D, has_cls, want_dx=True, dw=N
     return dx, dw, dbias, (dcls if has_cls else None)
 
 
+# ------------------------------------------------------------------------------------------------ quadtree patcher
+def quadtree_build(edges, fixed_length):
+    """edges uint8 [B, H, W] (0 / 255) -> (nodes int32 [B, L, 4] = (x1, x2, y1, y2), values int32 [B, L], count int32 [B],
+    seq_ps fp32 [B, L, 3] = (size, centre x, centre y))"""
+    L = _l.load()
+    _chk(edges, "quadtree_build.edges")
+    if edges.dtype != torch.uint8 or edges.dim() != 3:
+        raise TypeError("quadtree_build: edges must be uint8 [B, H, W]")
+    B, H, W = edges.shape
+    dev = edges.device
+    nodes = torch.empty((B, fixed_length, 4), dtype=torch.int32, device=dev)
+    values = torch.empty((B, fixed_length), dtype=torch.int32, device=dev)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
+    seq_ps = torch.empty((B, fixed_length, 3), dtype=torch.float32, device=dev)
+    ws = workspace(L.ucfvit_quadtree_workspace(B, H, W), dev)
+    _l.check(L.ucfvit_quadtree_build(edges.data_ptr(), nodes.data_ptr(), values.data_ptr(), count.data_ptr(), seq_ps.data_ptr(), B, H, W,
+                                     fixed_length, ws.data_ptr(), _stream()), "ucfvit_quadtree_build")
+    return nodes, values, count, seq_ps
+
+
+def quadtree_serialize(img, nodes, count, patch):
+    """img fp32 [B, H, W, C], nodes / count from quadtree_build -> x [B, C, L, patch*patch] (the reference's plain reshape of the
+    [L, p, p, C] patch list, transform.py:42-48) = the model input of adaptive_patching=True"""
+    L = _l.load()
+    _chk(img, "quadtree_serialize.img"), _chk(nodes, "quadtree_serialize.nodes"), _chk(count, "quadtree_serialize.count")
+    if img.dtype != torch.float32 or img.dim() != 4 or nodes.dtype != torch.int32 or count.dtype != torch.int32:
+        raise TypeError("quadtree_serialize: img fp32 [B, H, W, C], nodes int32 [B, L, 4], count int32 [B]")
+    B, H, W, C = img.shape
+    S = nodes.shape[1]
+    seq = torch.empty((B, S, patch, patch, C), dtype=torch.float32, device=img.device)
+    _l.check(L.ucfvit_quadtree_serialize(img.data_ptr(), nodes.data_ptr(), count.data_ptr(), seq.data_ptr(), B, H, W, C, S, patch, _stream()),
+             "ucfvit_quadtree_serialize")
+    return seq.view(B, C, S, patch * patch)
+
+
 def cross_entropy(logits, labels, grad_scale=1.0, want_grad=True):
     """returns (loss fp32 scalar tensor, dlogits or None, row_loss)"""
     L = _l.load()
