@@ -204,6 +204,19 @@ int ucfvit_quadtree_build(const uint8_t* edges, int32_t* nodes, int32_t* values,
 int ucfvit_quadtree_serialize(const float* img, const int32_t* nodes, const int32_t* count, float* seq, int64_t B, int64_t H, int64_t W,
                               int64_t C, int64_t L, int64_t p, void* stream);
 
+/* Octree patcher for 3-D volumes (dataloaders/octree.py:66-151 FixedOctTree, transform.py:57-132 Patchify_3D's tree + serialize part).
+ * domain uint8 [B][N][N][N] indexed [z][y][x] (cubic, N <= 256); value = sum(region) / norm_factor (norm_factor = int(255 / channels),
+ * transform.py:120); children in the reference's order (x fastest, then y, then z); fixed_length L must be 7n+1; stop when the first
+ * maximum node is 2 wide.  nodes int32 [B][L][6] = (x1, x2, y1, y2, z1, z2), values, count as for the quadtree; seq_ps fp32 [B][L][4] =
+ * (size, centre x, y, z), padding size 0 / centre -1.  workspace: ucfvit_octree_workspace bytes.
+ * ucfvit_octree_serialize: img fp32 [B][N][N][N][C]; leaf img[z1:z2, y1:y2, x1:x2, :] -> p^3 by linear interpolation with aligned corners
+ * (the reference's scipy RegularGridInterpolator on linspace(0, n, n) -> linspace(0, n, p)), seq fp32 [B][L][p][p][p][C]. */
+int64_t ucfvit_octree_workspace(int64_t B, int64_t N);
+int ucfvit_octree_build(const uint8_t* domain, int32_t* nodes, int32_t* values, int32_t* count, float* seq_ps, int64_t B, int64_t N, int64_t L,
+                        int norm_factor, void* workspace, void* stream);
+int ucfvit_octree_serialize(const float* img, const int32_t* nodes, const int32_t* count, float* seq, int64_t B, int64_t N, int64_t C,
+                            int64_t L, int64_t p, void* stream);
+
 /* Softmax cross-entropy, mean over the batch (nn.CrossEntropyLoss, training_scripts/train_class_simple.py:24-30).
  * logits [B][C] dtype, labels int64 [B]; loss: fp32 scalar (device); row_loss: fp32 [B] per-sample losses (also scratch);
  * dlogits [B][C] dtype = grad_scale*(softmax - onehot)/B, or NULL. */

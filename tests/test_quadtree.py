@@ -100,3 +100,71 @@ def test_patchify_module_feeds_the_adaptive_model():
             use_adaptive_pos_emb=True).cuda()
     out = m(seq, ["red", "green", "blue"], torch.cat([size.unsqueeze(-1), pos], dim=-1))
     assert tuple(out.shape) == (B, 5) and bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------------------------------------------ octree (3-D volumes)
+def _ocases():
+    g = load_golden("octree_nodes.npz")
+    for i in range(int(g["n_cases"])):
+        yield i, g, g[f"domain{i}"].numpy(), int(g[f"L{i}"]), int(g[f"norm{i}"]), int(g[f"p{i}"]), g[f"nodes{i}"].numpy(), g[f"values{i}"].numpy()
+
+
+def test_oracle_octree_matches_reference():
+    """node lists bit-exact; the trilinear leaf resampling against the reference's own scipy RegularGridInterpolator output"""
+    for i, g, dom, L, norm, p, nodes, vals in _ocases():
+        n, v = QR.build_octree(dom, L, norm)
+        assert np.array_equal(np.array(n, dtype=np.int32), nodes), i
+        assert np.array_equal(np.array(v, dtype=np.int64), vals), i
+        if p:
+            seq, size, pos = QR.serialize3(g[f"img{i}"].numpy(), n, L, p)
+            assert np.abs(seq - g[f"seq{i}"].numpy()).max() < 1e-5, i
+            assert np.array_equal(size, g[f"size{i}"].numpy()) and np.array_equal(pos, g[f"pos{i}"].numpy()), i
+
+
+@pytest.mark.gpu
+def test_hip_octree_is_bit_exact_and_serializes_like_the_reference():
+    from UCF_VIT._hip import ops
+    for i, g, dom, L, norm, p, nodes, vals in _ocases():
+        d = torch.from_numpy(dom).unsqueeze(0).cuda()
+        out_nodes, out_vals, count, seq_ps = ops.octree_build(d, L, norm)
+        n = int(count[0])
+        assert n == len(nodes), (i, n, len(nodes))
+        assert np.array_equal(out_nodes[0, :n].cpu().numpy(), nodes), i
+        assert np.array_equal(out_vals[0, :n].cpu().numpy().astype(np.int64), vals), i
+        if p:
+            img = g[f"img{i}"].cuda().unsqueeze(0)
+            seq = ops.octree_serialize(img, out_nodes, count, p, flat=False)                 # [1, L, p, p, p, C]
+            assert np.abs(seq[0].cpu().numpy() - g[f"seq{i}"].numpy()).max() < 1e-5, i
+            assert np.array_equal(seq_ps[0, :, 0].cpu().numpy(), g[f"size{i}"].numpy())
+            assert np.array_equal(seq_ps[0, :, 1:].cpu().numpy(), g[f"pos{i}"].numpy())
+
+
+@pytest.mark.gpu
+def test_hip_octree_batched_vs_oracle():
+    from UCF_VIT._hip import ops
+    rng = np.random.Generator(np.random.PCG64(17))
+    B, N, L, p = 4, 32, 120, 4
+    doms = np.stack([(rng.random((N, N, N)) < d).astype(np.uint8) * 255 for d in (0.0, 0.002, 0.05, 0.6)])
+    imgs = rng.random((B, N, N, N, 2)).astype(np.float32)
+    out_nodes, out_vals, count, seq_ps = ops.octree_build(torch.from_numpy(doms).cuda(), L, 255)
+    seq = ops.octree_serialize(torch.from_numpy(imgs).cuda(), out_nodes, count, p, flat=False)
+    for b in range(B):
+        n, v = QR.build_octree(doms[b], L, 255)
+        assert int(count[b]) == len(n), b
+        assert np.array_equal(out_nodes[b, :len(n)].cpu().numpy(), np.array(n, dtype=np.int32)), b
+        want, size, pos = QR.serialize3(imgs[b], n, L, p)
+        assert np.abs(seq[b].cpu().numpy() - want).max() < 1e-5, b
+        assert np.array_equal(seq_ps[b, :, 0].cpu().numpy(), size) and np.array_equal(seq_ps[b, :, 1:].cpu().numpy(), pos)
+
+
+@pytest.mark.gpu
+def test_patchify_3d_module_shapes_and_tiling():
+    from UCF_VIT.dataloaders.transform import Patchify_3D
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, N, L, p = 2, 32, 64, 4
+    dom = torch.from_numpy((rng.random((B, N, N, N)) < 0.02).astype(np.uint8) * 255).cuda()
+    vol = torch.from_numpy(rng.random((B, N, N, N, 1)).astype(np.float32)).cuda()
+    seq, size, pos, nodes, count = Patchify_3D(L, p, 1)(vol, dom)
+    assert tuple(seq.shape) == (B, 1, L, p ** 3) and tuple(size.shape) == (B, L) and tuple(pos.shape) == (B, L, 3)
+    ext = nodes[..., 1::2] - nodes[..., 0::2]
+    assert bool((ext.prod(dim=-1).sum(dim=1) == N ** 3).all())          # the leaves tile the volume exactly once

@@ -55,6 +55,9 @@ SIGNATURES = {
     "ucfvit_tokens_bwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
     "ucfvit_seq_patches": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "ucfvit_quadtree_workspace": (_I64, [_I64, _I64, _I64]),
+    "ucfvit_octree_workspace": (_I64, [_I64, _I64]),
+    "ucfvit_octree_build": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P]),
+    "ucfvit_octree_serialize": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "ucfvit_quadtree_build": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "ucfvit_quadtree_serialize": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "ucfvit_adaptive_pos_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),

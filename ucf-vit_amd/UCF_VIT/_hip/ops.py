@@ -384,6 +384,39 @@ def quadtree_serialize(img, nodes, count, patch):
     return seq.view(B, C, S, patch * patch)
 
 
+def octree_build(domain, fixed_length, norm_factor=255):
+    """domain uint8 [B, N, N, N] ([z][y][x]) -> (nodes int32 [B, L, 6], values int32 [B, L], count int32 [B], seq_ps fp32 [B, L, 4])"""
+    L = _l.load()
+    _chk(domain, "octree_build.domain")
+    if domain.dtype != torch.uint8 or domain.dim() != 4 or not (domain.shape[1] == domain.shape[2] == domain.shape[3]):
+        raise TypeError("octree_build: domain must be a batch of cubic uint8 volumes [B, N, N, N]")
+    B, N = domain.shape[0], domain.shape[1]
+    dev = domain.device
+    nodes = torch.empty((B, fixed_length, 6), dtype=torch.int32, device=dev)
+    values = torch.empty((B, fixed_length), dtype=torch.int32, device=dev)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
+    seq_ps = torch.empty((B, fixed_length, 4), dtype=torch.float32, device=dev)
+    ws = workspace(L.ucfvit_octree_workspace(B, N), dev)
+    _l.check(L.ucfvit_octree_build(domain.data_ptr(), nodes.data_ptr(), values.data_ptr(), count.data_ptr(), seq_ps.data_ptr(), B, N,
+                                   fixed_length, int(norm_factor), ws.data_ptr(), _stream()), "ucfvit_octree_build")
+    return nodes, values, count, seq_ps
+
+
+def octree_serialize(img, nodes, count, patch, flat=True):
+    """img fp32 [B, N, N, N, C] -> x [B, C, L, patch**3] (Patchify_3D's plain reshape, transform.py:123-126) or, flat=False, the patch list
+    [B, L, p, p, p, C]"""
+    L = _l.load()
+    _chk(img, "octree_serialize.img"), _chk(nodes, "octree_serialize.nodes"), _chk(count, "octree_serialize.count")
+    if img.dtype != torch.float32 or img.dim() != 5 or nodes.dtype != torch.int32 or count.dtype != torch.int32:
+        raise TypeError("octree_serialize: img fp32 [B, N, N, N, C], nodes int32 [B, L, 6], count int32 [B]")
+    B, N, _, _, C = img.shape
+    S = nodes.shape[1]
+    seq = torch.empty((B, S, patch, patch, patch, C), dtype=torch.float32, device=img.device)
+    _l.check(L.ucfvit_octree_serialize(img.data_ptr(), nodes.data_ptr(), count.data_ptr(), seq.data_ptr(), B, N, C, S, patch, _stream()),
+             "ucfvit_octree_serialize")
+    return seq.view(B, C, S, patch ** 3) if flat else seq
+
+
 def cross_entropy(logits, labels, grad_scale=1.0, want_grad=True):
     """returns (loss fp32 scalar tensor, dlogits or None, row_loss)"""
     L = _l.load()

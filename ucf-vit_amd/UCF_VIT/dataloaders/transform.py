@@ -37,3 +37,29 @@ class Patchify(torch.nn.Module):
         nodes, _, count, seq_ps = ops.quadtree_build(edges, self.fixed_length)
         seq_img = ops.quadtree_serialize(img, nodes, count, self.patch_size)
         return seq_img, seq_ps[..., 0], seq_ps[..., 1:], nodes, count
+
+
+class Patchify_3D(torch.nn.Module):
+    """3-D counterpart (reference transform.py:57-132 + octree.py:66-151): forward(vol, domain) -> (seq_img, seq_size, seq_pos, nodes, count)
+       vol    fp32 [B, N, N, N, C] (cubic, channels last), domain uint8 [B, N, N, N] = the reference's `edges` volume
+              (edge counter * norm_factor, norm_factor = int(255 / num_channels), transform.py:118-121)
+       seq_img fp32 [B, C, fixed_length, patch_size**3], seq_size [B, fixed_length], seq_pos [B, fixed_length, 3]
+       nodes int32 [B, fixed_length, 6] = (x1, x2, y1, y2, z1, z2); leaves are resampled with the reference's aligned-corner linear rule."""
+
+    def __init__(self, fixed_length=729, patch_size=8, num_channels=1):
+        super().__init__()
+        if fixed_length % 7 != 1:
+            raise ValueError("Octtree fixed length needs to be 7n+1, where n is some integer")       # train_unetr_simple.py:218
+        self.fixed_length, self.patch_size, self.num_channels = fixed_length, patch_size, num_channels
+        self.norm_factor = int(255 / num_channels)
+
+    @torch.no_grad()
+    def forward(self, vol, domain):
+        if vol.dim() != 5 or vol.shape[-1] != self.num_channels:
+            raise ValueError(f"Patchify_3D: vol must be [B, N, N, N, C={self.num_channels}], got {tuple(vol.shape)}")
+        vol = vol if vol.dtype == torch.float32 else vol.float()
+        vol = vol if vol.is_contiguous() else vol.contiguous()
+        domain = domain if domain.is_contiguous() else domain.contiguous()
+        nodes, _, count, seq_ps = ops.octree_build(domain, self.fixed_length, self.norm_factor)
+        seq_img = ops.octree_serialize(vol, nodes, count, self.patch_size)
+        return seq_img, seq_ps[..., 0], seq_ps[..., 1:], nodes, count
