@@ -98,18 +98,41 @@ def seq_to_pseudo_image(seq, sqrt_len, patch_size, twoD):
 class SyntheticSeqLoader:
     """per-rank synthetic batches shaped like the reference's adaptive-patching dataloader output (train_class_simple.py:322-337):
     seq fp32 [B, C, S, P] (S = fixed_length resized patches of P = p^nd pixels), seq_ps fp32 [B, S, 3|4] = (size, position...),
-    label.  The quadtree / octree patcher itself is a data-pipeline 'next' row."""
+    label.  When fixed_length fits the tree rule (3n+1 / 7n+1) and the images are square, synthetic images and synthetic edge maps
+    go through the GPU quadtree / octree patcher (UCF_VIT.dataloaders.transform); otherwise the sequences are drawn directly."""
 
     def __init__(self, batch_size, in_chans, img_size, patch_size, fixed_length, num_classes, iters, device, seed):
         nd = len(img_size)
         self.shape = (batch_size, in_chans, fixed_length, patch_size ** nd)
         self.nd, self.img = nd, min(img_size)
+        self.square = len(set(img_size)) == 1          # the quadtree / octree patchers work on square images / cubic volumes
         self.num_classes, self.iters, self.device, self.seed = num_classes, iters, device, seed
+
+    def _patchified(self, g):
+        """synthetic images + synthetic edge maps through the GPU patcher (UCF_VIT.dataloaders.transform, the device-side counterpart
+        of the reference's Patchify transform): the same tensors the reference dataloader hands to the training step"""
+        from UCF_VIT.dataloaders.transform import Patchify, Patchify_3D
+        B, C, S, P = self.shape
+        n, p = self.img, round(P ** (1.0 / self.nd))
+        dev = self.device
+        img = torch.randint(0, 256, (B,) + (n,) * self.nd + (C,), generator=g).float().to(dev)
+        edges = ((torch.rand((B,) + (n,) * self.nd, generator=g) < 0.02).to(torch.uint8) * 255).to(dev)
+        if self.nd == 2:
+            seq, size, pos, _, _ = Patchify(S, p, C)(img, edges)
+        else:
+            seq, size, pos, _, _ = Patchify_3D(S, p, C)(img, edges)
+        return seq, torch.cat([size.unsqueeze(-1), pos], dim=-1)
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed)
         B, _, S, _ = self.shape
+        tree_ok = S % (3 if self.nd == 2 else 7) == 1 and (self.nd == 2 or self.img <= 256)
         for _ in range(self.iters):
+            if tree_ok and self.square:
+                seq, seq_ps = self._patchified(g)
+                label = torch.randint(0, max(self.num_classes, 1), (B,), generator=g)
+                yield seq, seq_ps, label.to(self.device, non_blocking=True)
+                continue
             seq = torch.randint(0, 256, self.shape, generator=g).float()
             size = 2.0 ** torch.randint(1, 6, (B, S, 1), generator=g).float()
             pos = torch.randint(0, self.img, (B, S, self.nd), generator=g).float()
