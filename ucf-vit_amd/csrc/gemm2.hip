@@ -441,20 +441,19 @@ __device__ __forceinline__ void epi4_row8(float* v, int m, int n, OutT* __restri
 }
 
 constexpr int G4_STAGE_OFF = 2 * (256 + 256) * 128;            // after the two pipeline buffers
-constexpr int G4_PADW = 64 + 4;                                // staged row: 64 fp32 columns + pad
-constexpr int G4_SMEM = G4_STAGE_OFF + 4 * 16 * G4_PADW * 4;   // 148480 bytes
+constexpr int G4_PADW = 32 + 4;                                // staged row: 32 fp32 columns + pad
+constexpr int G4_SMEM = G4_STAGE_OFF + 4 * 32 * G4_PADW * 4;   // 149504 bytes
 
 template <typename OutT>
 __global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C, int M, int N,
                                                     int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m, int tiles_n) {
     constexpr int KC = UCFVIT_LAYOUT_KC;
-    constexpr int BM = 256, BN = 256, FM = 8, FN = 8;
+    constexpr int BM = 256, BN = 256;
     constexpr int A_BYTES = BM * 128, BUF = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
-    const int g = lane >> 4, li = lane & 15;
     const int tiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
     const int nk = (K + BK2 - 1) / BK2;
     const int klast = K - (nk - 1) * BK2;
@@ -480,7 +479,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = (wave * 8 + i) * 8 + (lane >> 3);
-            const int gslot = (lane & 7) ^ (row & 7);
+            const int gslot = (lane & 7) ^ ((row >> 1) & 7);      // this kernel's swizzle (see the fragment reads)
             int gr = r0 + row;
             gr = gr < R ? gr : R - 1;
             off[i] = (unsigned)(((int64_t)gr * ld + gslot * 8) * 2);
@@ -491,10 +490,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, 
     auto prefetch = [&]() {
         if (!p_valid) return;
         char* dst = smem + (pf_it & 1) * BUF;
-        if (p_kt == nk - 1 && klast < BK2) {              // ragged last K-tile: lanes past K read the zero page
-            issue_tile<KC, BM, 4>(A, lda, p_m0, p_kt * BK2, M, dst, wave, lane, klast);
-            issue_tile<KC, BN, 4>(B, ldb, p_n0, p_kt * BK2, N, dst + A_BYTES, wave, lane, klast);
-        } else {
+        {                                                 // (K is a multiple of 64 here: the dispatcher sends ragged K elsewhere)
             const char* ak = reinterpret_cast<const char*>(A) + (int64_t)p_kt * (BK2 * 2);
             const char* bk = reinterpret_cast<const char*>(B) + (int64_t)p_kt * (BK2 * 2);
 #pragma unroll
@@ -518,110 +514,136 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, 
     prefetch();
     prefetch();
 
-    bf16x8 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
-#define G4_READ(fa_, fb_, buf_, c_)                                                            \
+    // ---- 32x32x16 MFMAs (a single wave issues this shape at the full matrix-pipe rate; with 16x16x32 one wave per SIMD tops out at
+    // about two thirds of it: tools/mfma_peak.hip).  Wave tile = 4 x 4 tiles of 32 x 32, a K-tile = 4 steps of 16.
+    // Fragment of rows r0..r0+31, step kk: lane l reads the 8 contraction elements of slot 2 kk + (l >> 5) in row r0 + (l & 31).
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int TI = 4, TJ = 4;
+    u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // Fragment reads are inline asm too (ds_read_b128 with one address register per operand and step: the 32-row tile index is an
+    // immediate offset), so hipcc neither drains lgkmcnt in front of an MFMA nor re-orders anything: the read burst of step s+1 is
+    // issued FIRST, then `s_waitcnt lgkmcnt(8)` lets exactly those eight stay in flight while the 16 MFMAs of step s issue.
+    //   byte offset of (row r0 + frow, slot 2 kk + fhalf) = (r0 + frow) * 128 + (((2 kk + fhalf) ^ ((frow >> 1) & 7)) << 4),  r0 = 32 i (+ wm)
+    // Swizzle: a ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) and a row starts at bank
+    // 0 or 32 by its parity, so the 8 even and the 8 odd rows of a group must use 8 different 16-byte slots: (row >> 1) & 7 does that
+    // for the 32-row fragments of this MFMA shape (the (row & 7) swizzle of the 16-row kernels is 2-way conflicted here).
+    unsigned xk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) xk[kk] = (unsigned)((((2 * kk + fhalf) ^ ((frow >> 1) & 7)) << 4) + frow * 128);
+    const unsigned ldsA = lds_addr(smem) + (unsigned)(wm * 128), ldsB = lds_addr(smem) + (unsigned)(A_BYTES + wn * 128);
+#ifdef UCFVIT_DBG_G4_NOREAD   /* timing experiment: no fragment reads at all (wrong results) */
+#define G4_RD(dst_, addr_, off_) asm volatile("" : "+v"(dst_) : "v"(addr_))
+#else
+#define G4_RD(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
+#endif
+#define G4_READ(fa_, fb_, bufoff_, kk_)                                                        \
     do {                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < FN; ++j) fb_[j] = load_frag2<KC, BN>((buf_) + A_BYTES, wn + 16 * j, c_, lane); \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i) fa_[i] = load_frag2<KC, BM>((buf_), wm + 16 * i, c_, lane);          \
+        const unsigned aa = ldsA + (bufoff_) + xk[kk_], ab = ldsB + (bufoff_) + xk[kk_];       \
+        G4_RD(fb_[0], ab, 0); G4_RD(fb_[1], ab, 4096); G4_RD(fb_[2], ab, 8192); G4_RD(fb_[3], ab, 12288); \
+        G4_RD(fa_[0], aa, 0); G4_RD(fa_[1], aa, 4096); G4_RD(fa_[2], aa, 8192); G4_RD(fa_[3], aa, 12288); \
     } while (0)
 // The MFMAs are inline asm with the accumulator tied in place in an AGPR ("+a"): with all 256 AGPRs holding accumulators hipcc's
-// allocator otherwise un-ties destination and addend of most MFMAs and copies 4 AGPRs in front of each (measured: 2x slower loop).
+// allocator otherwise un-ties destination and addend of most MFMAs and copies the tile in front of each (measured: 2x slower loop).
+// Roles swapped as in the other kernels: D[n][m], lane l holds m = l & 31 and n = 8 b + 4 (l >> 5) + r in register 4 b + r.
 #define G4_MFMA_ROWS(fa_, fb_, I0_, I1_)                                                       \
     do {                                                                                       \
         _Pragma("unroll") for (int i = I0_; i < I1_; ++i)                                      \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb_[j]), "v"(fa_[i])); \
+            _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                     \
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb_[j]), "v"(fa_[i])); \
     } while (0)
-#define G4_MFMA(fa_, fb_)                                                                      \
+// one step: read burst of the next step into the other set, counted wait for THIS step's set, 16 MFMAs
+#define G4_STEP(fa_, fb_, nfa_, nfb_, nbufoff_, nkk_, do_read_)                                 \
     do {                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i)                                         \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                     \
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb_[j]), "v"(fa_[i])); \
+        if (do_read_) {                                                                        \
+            G4_READ(nfa_, nfb_, nbufoff_, nkk_);                                               \
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                 \
+        } else {                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+        }                                                                                      \
+        G4_MFMA_ROWS(fa_, fb_, 0, TI);                                                         \
     } while (0)
 
-    // the first K-tile: wait for it (the second one, 16 wave-instructions, may stay in flight), make it visible, read its first half
+    // the first K-tile: wait for it (the second one, 16 wave-instructions, may stay in flight), make it visible, read its first step
     if (nk > 1 || p_valid || p_round > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int it = 0;
-    G4_READ(fa0, fb0, smem, 0);      // (hipcc places the lgkmcnt waits of the fragment sets itself, counted, in front of their first MFMA)
+    G4_READ(fa0, fb0, 0u, 0);
 
     for (;;) {
         const int m0 = c_m0, n0 = c_n0;
-        f32x4 acc[FM][FN];
+        f32x16 acc[TI][TJ];
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // is there an output tile after this one?
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         int n_m0 = 0, n_n0 = 0;
         const bool has_next = tile_at(c_round + 1, n_m0, n_n0);
 #pragma clang loop unroll(disable)
         for (int kt = 0; kt < nk; ++kt, ++it) {
-            const char* buf = smem + (it & 1) * BUF;
-            const char* nbuf = smem + ((it + 1) & 1) * BUF;
-            // (hipcc drains lgkmcnt in front of the first asm MFMA that uses a loaded register: start on set 0 first, then issue the
-            // reads of the second half of this K-tile into set 1, so that drain only meets reads that completed long ago)
-            G4_MFMA_ROWS(fa0, fb0, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            G4_READ(fa1, fb1, buf, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            G4_MFMA_ROWS(fa0, fb0, 1, FM);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my reads of `buf` are done; my pieces of K-tile it+1 have landed
+            const unsigned boff = (unsigned)((it & 1) * BUF), nboff = (unsigned)(((it + 1) & 1) * BUF);
+            G4_STEP(fa0, fb0, fa1, fb1, boff, 1, true);
+            G4_STEP(fa1, fb1, fa0, fb0, boff, 2, true);
+            // step 2 -> 3: the last reads of this K-tile go out, then everything this wave has read or DMA-issued is waited for
+            G4_READ(fa1, fb1, boff, 3);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            G4_MFMA_ROWS(fa0, fb0, 0, TI);
+#ifdef UCFVIT_DBG_G4_NOVM
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my reads of this K-tile are done; my DMA pieces of K-tile it+1 have landed
+#endif
+#ifndef UCFVIT_DBG_G4_NOBAR
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch();                                   // K-tile it+2 -> `buf`
+#endif
+#ifndef UCFVIT_DBG_G4_NODMA
+            prefetch();                                     // K-tile it+2 -> this K-tile's buffer
+#endif
             const bool more = (kt + 1 < nk) || has_next;
-            G4_MFMA_ROWS(fa1, fb1, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) G4_READ(fa0, fb0, nbuf, 0);         // first half of the next K-tile (possibly of the next output tile)
-            __builtin_amdgcn_sched_barrier(0);
-            G4_MFMA_ROWS(fa1, fb1, 1, FM);
-            __builtin_amdgcn_sched_barrier(0);
+            G4_STEP(fa1, fb1, fa0, fb0, nboff, 0, more);    // first step of the next K-tile (possibly of the next output tile)
         }
 
         // the asm MFMAs are opaque to the hazard recogniser: let the last results retire before the accumulators are read
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        // ---- epilogue: 16-row strips of the wave's 128x128 block, each as two 64-column halves through a wave-private staging strip.
-        // The strip loop is a real loop (one copy of the row code); the accumulators keep compile-time indices through the switch.
-        float* stage = reinterpret_cast<float*>(smem + G4_STAGE_OFF) + wave * (16 * G4_PADW);
-        const int prow = lane >> 3, pcol = (lane & 7) * 8;
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // ---- epilogue: one 32 x 32 accumulator tile at a time through a wave-private staging tile.  The tile-row loop is a real loop
+        // (one copy of the row code); the accumulators keep compile-time indices through the switch.
+        float* stage = reinterpret_cast<float*>(smem + G4_STAGE_OFF) + wave * (32 * G4_PADW);
+        const int prow = lane >> 2, pcol = (lane & 3) * 8;
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < FM; ++i) {
-            f32x4 row[FN];
-#define G4_TAKE(I_) _Pragma("unroll") for (int j = 0; j < FN; ++j) row[j] = acc[I_][j]
+        for (int i = 0; i < TI; ++i) {
+            f32x16 row[TJ];
+#define G4_TAKE(I_) _Pragma("unroll") for (int j = 0; j < TJ; ++j) row[j] = acc[I_][j]
             switch (i) {
                 case 0: G4_TAKE(0); break;
                 case 1: G4_TAKE(1); break;
                 case 2: G4_TAKE(2); break;
-                case 3: G4_TAKE(3); break;
-                case 4: G4_TAKE(4); break;
-                case 5: G4_TAKE(5); break;
-                case 6: G4_TAKE(6); break;
-                default: G4_TAKE(7); break;
+                default: G4_TAKE(3); break;
             }
 #undef G4_TAKE
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int j = 0; j < TJ; ++j) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    f32x4 v = row[4 * h + jj];
-                    const int n = n0 + wn + 16 * (4 * h + jj) + 4 * g;
+                for (int b = 0; b < 4; ++b) {
+                    const int nl = 8 * b + 4 * fhalf;
+                    f32x4 v = {row[j][4 * b], row[j][4 * b + 1], row[j][4 * b + 2], row[j][4 * b + 3]};
+                    const int n = n0 + wn + 32 * j + nl;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= ep.alpha;
                     if (ep.bias && n < N) {
-                        const Vec4<bf16> b = *reinterpret_cast<const Vec4<bf16>*>(ep.bias + n);
+                        const Vec4<bf16> bb = *reinterpret_cast<const Vec4<bf16>*>(ep.bias + n);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += b.get(r);
+                        for (int r = 0; r < 4; ++r) v[r] += bb.get(r);
                     }
-                    *reinterpret_cast<f32x4*>(stage + li * G4_PADW + 16 * jj + 4 * g) = v;
+                    *reinterpret_cast<f32x4*>(stage + frow * G4_PADW + nl) = v;
                 }
 #pragma unroll
-                for (int rr = 0; rr < 16; rr += 8) {
+                for (int rr = 0; rr < 32; rr += 16) {
                     const int rw = rr + prow;
-                    const int m = m0 + wm + 16 * i + rw;
-                    const int n = n0 + wn + 64 * h + pcol;
+                    const int m = m0 + wm + 32 * i + rw;
+                    const int n = n0 + wn + 32 * j + pcol;
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + rw * G4_PADW + pcol);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + rw * G4_PADW + pcol + 4);
                     if (m >= M || n >= N) continue;
@@ -635,8 +657,9 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, 
         c_m0 = n_m0;
         c_n0 = n_n0;
     }
+#undef G4_RD
+#undef G4_STEP
 #undef G4_READ
-#undef G4_MFMA
 #undef G4_MFMA_ROWS
 }
 
@@ -1466,7 +1489,8 @@ int dispatch_tile(const ucfvit_gemm_desc* d, const Plan2& p, const Epi2& ep, hip
     const int64_t a_bytes = ((d->a_layout == UCFVIT_LAYOUT_KC ? d->M : d->K) * d->lda) * 2;
     const int64_t b_bytes = ((d->b_layout == UCFVIT_LAYOUT_KC ? d->N : d->K) * d->ldb) * 2;
     if constexpr (LA == UCFVIT_LAYOUT_KC && LB == UCFVIT_LAYOUT_KC) {
-        if (p.big && w4_enabled() && p.splits == 1 && !ep.slab && !ep.cs_partial && d->K >= 2 * BK2 && a_bytes < (1ll << 32) && b_bytes < (1ll << 32))
+        if (p.big && w4_enabled() && p.splits == 1 && !ep.slab && !ep.cs_partial && d->K >= 2 * BK2 && d->K % BK2 == 0 && a_bytes < (1ll << 32) &&
+            b_bytes < (1ll << 32))
             return launch4<OutT>(d, ep, s);
     }
     if (p.big && pp_enabled() && a_bytes < (1ll << 32) && b_bytes < (1ll << 32)) return launch3<LA, LB, OutT>(d, p, ep, s);
