@@ -134,7 +134,12 @@ struct Epi2 {
 
 // logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
 __device__ __forceinline__ void tile_origin(int t, int tiles_m, int tiles_n, int BM, int BN, int& m0, int& n0) {
-    constexpr int BAND = 8;
+#ifdef UCFVIT_DBG_BAND8
+    const int BAND = 8;
+#else
+    // 12 N-tiles (the qkv projection: N = 3072) as three bands of 4 rather than 8 + 4: every XCD block is 8 x 4 tiles
+    const int BAND = (tiles_n > 8 && tiles_n % 8 != 0 && tiles_n % 4 == 0) ? 4 : 8;
+#endif
     const int band_tiles = BAND * tiles_m;
     const int band = t / band_tiles;
     const int band_w = min(BAND, tiles_n - band * BAND);
