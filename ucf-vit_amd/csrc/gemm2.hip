@@ -132,13 +132,16 @@ struct Epi2 {
     float* cs_partial; // column sums of the output per 128-row block: [2 * tiles_m][N] (CS instantiations only), or NULL
 };
 
+__device__ int g_band_override = 0;      // experiments: UCFVIT_GEMM_BAND=n forces the band width (0 = the rule below)
+
 // logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
 __device__ __forceinline__ void tile_origin(int t, int tiles_m, int tiles_n, int BM, int BN, int& m0, int& n0) {
 #ifdef UCFVIT_DBG_BAND8
     const int BAND = 8;
 #else
     // 12 N-tiles (the qkv projection: N = 3072) as three bands of 4 rather than 8 + 4: every XCD block is 8 x 4 tiles
-    const int BAND = (tiles_n > 8 && tiles_n % 8 != 0 && tiles_n % 4 == 0) ? 4 : 8;
+    const int ov = g_band_override;
+    const int BAND = ov ? ov : ((tiles_n > 8 && tiles_n % 8 != 0 && tiles_n % 4 == 0) ? 4 : 8);
 #endif
     const int band_tiles = BAND * tiles_m;
     const int band = t / band_tiles;
@@ -1382,6 +1385,15 @@ int launch3g(const GroupsT<NP>& gt, int K, const Epi2& ep, int splits, int k_per
     // persistent grid = the CUs this launch may count on.  One 512-thread workgroup fills a CU's register file, so a CU that hosts a
     // wave of another kernel (an RCCL all-reduce overlapping backward) cannot take one: a grid larger than the free CUs leaves
     // workgroups waiting for a whole tile list.  UCFVIT_GEMM_CUS (default 256) lets a multi-GPU job reserve the CUs RCCL uses.
+    static bool band_done = false;
+    if (!band_done) {
+        band_done = true;
+        const char* eb = getenv("UCFVIT_GEMM_BAND");
+        if (eb) {
+            int v = atoi(eb);
+            if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_band_override), &v, sizeof(int));
+        }
+    }
     static int cus = 0;
     if (!cus) {
         const char* e = getenv("UCFVIT_GEMM_CUS");
