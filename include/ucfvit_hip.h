@@ -217,6 +217,18 @@ int ucfvit_octree_build(const uint8_t* domain, int32_t* nodes, int32_t* values, 
 int ucfvit_octree_serialize(const float* img, const int32_t* nodes, const int32_t* count, float* seq, int64_t B, int64_t N, int64_t C,
                             int64_t L, int64_t p, void* stream);
 
+/* Variable aggregation (VariableMapping_Attention, simple/building_blocks.py:301-373, called by VIT.aggregate_variables,
+ * simple/arch.py:414-432) with one aggregated variable: for every token row r and head h,
+ *     p_v = softmax_v(scale * q_h . k[v][r][h]),  out[r][h] = sum_v p_v * v[v][r][h].
+ * kv [V][R][2D] `dtype` (the kv Linear applied to the V per-variable token embeddings: k = columns [0, D), v = [D, 2D)), q fp32 [D]
+ * (the q Linear applied to the learnt query), out [R][D] `dtype`, lse fp32 [R][H] (saved for backward).
+ * bwd: dkv [V][R][2D], dq_rows fp32 [R][D] (its column sums = the gradient of q; ucfvit_colsum).  head_dim | D, both multiples of
+ * 8 (bf16) / 4 (fp32), D <= 2048 (bf16) / 1024 (fp32), head_dim / 8 (4) a power of two. */
+int ucfvit_varagg_fwd(const void* kv, const float* q, void* out, float* lse, int64_t R, int64_t V, int64_t D, int64_t head_dim, float scale,
+                      int dtype, void* stream);
+int ucfvit_varagg_bwd(const void* kv, const float* q, const void* out, const float* lse, const void* dout, void* dkv, float* dq_rows, int64_t R,
+                      int64_t V, int64_t D, int64_t head_dim, float scale, int dtype, void* stream);
+
 /* Softmax cross-entropy, mean over the batch (nn.CrossEntropyLoss, training_scripts/train_class_simple.py:24-30).
  * logits [B][C] dtype, labels int64 [B]; loss: fp32 scalar (device); row_loss: fp32 [B] per-sample losses (also scratch);
  * dlogits [B][C] dtype = grad_scale*(softmax - onehot)/B, or NULL. */

@@ -137,6 +137,67 @@ def test_hip_data_parallel_bf16_gradient_transport_two_ranks():
         assert same and flat
 
 
+def _hip_dp_foreign_worker(rank, world, port, q):
+    """SAP: encoder gradients are written by the HIP kernels into the flat buffer, the transposed-convolution neck and the 1x1 header are
+    torch modules whose gradients autograd allocates itself: both kinds must come out as the mean over the ranks"""
+    for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from UCF_VIT.simple.arch import SAP
+        from UCF_VIT._hip.ddp import HipDataParallel
+        from UCF_VIT.utils.misc import configure_optimizer
+        from det_weights import det_state_dict, det_tensor
+        kw = dict(img_size=[32, 32], patch_size=8, in_chans=3, num_classes=3, embed_dim=64, depth=1, num_heads=2, sqrt_len=4, class_token=False,
+                  weight_init='skip')
+        torch.manual_seed(5)
+        m = SAP(**kw)
+        m.load_state_dict(det_state_dict(m, 300))
+        m = m.to("cuda:0")
+        xs = [det_tensor((2, 3, 32, 32), 310 + r) for r in range(world)]
+        # expected: mean over the ranks of the single-rank gradients (computed with an unwrapped copy of the same weights)
+        ref = SAP(**kw)
+        ref.load_state_dict(det_state_dict(ref, 300))
+        ref = ref.to("cuda:0")
+        exp = None
+        for r in range(world):
+            ref.zero_grad()
+            ref(xs[r].to("cuda:0"), None).float().square().mean().backward()
+            g = [p.grad.detach().clone() for p in ref.parameters()]
+            exp = g if exp is None else [a + b for a, b in zip(exp, g)]
+        ddp = HipDataParallel(m, bucket_mb=0.05)
+        opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 0.0)
+        ddp(xs[rank].to("cuda:0"), None).float().square().mean().backward()
+        torch.cuda.synchronize()
+        from conftest import rel_err
+        bad = [k for (k, p), e in zip(m.named_parameters(), exp) if p.grad is None or rel_err(p.grad, e / world) > 1e-3]
+        inflat = all(p.grad.data_ptr() == m._ucf_store.flat_g.data_ptr() + 4 * o for p, o in zip(m._ucf_store.params, m._ucf_store.offsets)
+                     if p.grad is not None)
+        opt.step()
+        q.put((rank, bad, inflat))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_data_parallel_reduces_torch_produced_gradients_too():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_dp_foreign_worker, args=(r, 2, 29574, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, inflat in res:
+        assert not bad, f"rank {rank}: gradient mismatch in {bad}"
+        assert inflat
+
+
 @pytest.mark.gpu
 def test_hip_data_parallel_two_ranks_share_one_gpu():
     """the HIP model + flat-buffer reducer + fused AdamW with world_size 2 (both ranks on the one GPU, gloo transport):

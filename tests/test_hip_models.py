@@ -200,6 +200,28 @@ def test_unetr_adaptive_sqrt_len_encoder_vs_oracle_and_trains():
     assert math.isfinite(gsum) and gsum > 0 and m.adaptive_pos_dep_emb[0].weight.grad is not None
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("name,single,variables,seed,chans", [("model_vit_varemb.npz", False, ["v", "q", "u"], 81, 3),
+                                                              ("model_vit_varemb_single.npz", True, ["t"], 83, 1)])
+def test_vit_variable_aggregation_vs_reference(name, single, variables, seed, chans, dtype, tol):
+    """VIT(use_varemb=True) (README "Variable Aggregation", arch.py:395-462, building_blocks.py:301-373) on adaptively patched input,
+    3 of 4 default variables passed out of order: logits, loss and every gradient (the token embeddings of the unused variable stay 0)"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    g = load_golden(name)
+    m = VIT(img_size=[32, 32], patch_size=8, in_chans=chans, num_classes=5, embed_dim=64, depth=2, num_heads=2, use_varemb=True,
+            default_vars=["u", "v", "t", "q"], single_channel=single, adaptive_patching=True, fixed_length=12, use_adaptive_pos_emb=True)
+    m.load_state_dict(det_state_dict(m, seed, keep=()))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    out = m(g["x"].to(DEV), variables, g["seq_ps"].to(DEV))
+    loss = cross_entropy_loss(out, g["labels"].to(DEV))
+    loss.backward()
+    assert rel_err(out.float(), g["logits"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    _check_grads_vs_golden(m, g, tol)
+
+
 def test_vit_adaptive_patching_trains_like_the_oracle():
     """10 AdamW steps on one adaptive batch (bf16 HIP path against the fp32 CPU oracle): same loss curve, loss goes down"""
     from oracle import ucf_vit_ref as R

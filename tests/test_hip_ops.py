@@ -501,3 +501,32 @@ print("ok")
 """ % os.path.join(ROOT, "ucf-vit_amd")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200, env=dict(os.environ, UCFVIT_GEMM_W4="1"))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V,R,D,dh", [(3, 24, 64, 32), (5, 1000, 1024, 64), (2, 333, 768, 64), (7, 130, 256, 128), (1, 50, 192, 64)])
+def test_variable_aggregation_attention_fwd_bwd(dtype, V, R, D, dh):
+    """softmax over the V variables of every token row with one shared query (building_blocks.py:336-366) against fp64 torch on the
+    same rounded inputs; D / vector width not a divisor of 256 (768) and a single variable (softmax = 1) included"""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(V * 1000 + R + D)
+    kv = torch.randn(V * R, 2 * D, generator=gen)
+    q = torch.randn(D, generator=gen)
+    dout = torch.randn(R, D, generator=gen)
+    H, scale = D // dh, dh ** -0.5
+    kvr = kv.to(dtype).double().requires_grad_(True)
+    qr = q.double().requires_grad_(True)
+    k, v = kvr.view(V, R, 2, H, dh).unbind(2)                                        # [V, R, H, dh]
+    s = (k * (qr.view(1, 1, H, dh) * scale)).sum(-1)                                   # [V, R, H]
+    p = s.softmax(dim=0)
+    want = (p.unsqueeze(-1) * v).sum(0).reshape(R, D)
+    want.backward(dout.to(dtype).double())
+    out, lse = ops.varagg_fwd(kv.to(DEV, dtype), q.to(DEV), V, R, D, dh, scale)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(out.float().cpu(), want.detach().float()) < tol
+    dkv, dq = ops.varagg_bwd(kv.to(DEV, dtype), q.to(DEV), out, lse, dout.to(DEV, dtype), V, R, D, dh, scale)
+    assert rel_err(dkv.float().cpu(), kvr.grad.float()) < (1e-4 if dtype == torch.float32 else 2e-2)
+    if V == 1:          # softmax over one variable is 1 whatever q is: the true gradient is exactly zero
+        assert float(dq.abs().max()) < 1e-4
+    else:
+        assert rel_err(dq.cpu(), qr.grad.float()) < (1e-4 if dtype == torch.float32 else 2e-2)

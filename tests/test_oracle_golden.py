@@ -168,6 +168,20 @@ def test_oracle_sap_adaptive():
     _check_grads(m, g)
 
 
+@pytest.mark.parametrize("name,single,variables,seed", [("model_vit_varemb.npz", False, ["v", "q", "u"], 81), ("model_vit_varemb_single.npz", True, ["t"], 83)])
+def test_oracle_vit_variable_aggregation(name, single, variables, seed):
+    """VIT(use_varemb=True) on adaptively patched input: per-variable token embeddings + variable embedding + VariableMapping_Attention"""
+    g = load_golden(name)
+    m = R.VarembVIT(patch_size=8, num_classes=5, embed_dim=64, depth=2, num_heads=2, fixed_length=12, default_vars=["u", "v", "t", "q"],
+                    single_channel=single)
+    m.load_state_dict(det_state_dict(m, seed, keep=()))
+    out = m(g["x"], variables, g["seq_ps"])
+    loss = torch.nn.CrossEntropyLoss()(out, g["labels"])
+    loss.backward()
+    assert rel_err(out, g["logits"]) < 1e-5 and abs(loss.item() - g["loss"].item()) < 1e-6
+    _check_grads(m, g)
+
+
 def test_oracle_vit_tiny_config_T():
     """BASELINE configs[0]: ViT-Tiny/16, catsdogs tile 256x256, 2 classes (un-normalised 0..255 pixels)"""
     g = load_golden("model_vit_tiny_catsdogs.npz")

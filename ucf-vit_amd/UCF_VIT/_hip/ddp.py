@@ -121,6 +121,15 @@ class HipDataParallel(nn.Module):
             self._callback_queued = True
             self._pending = [0] * len(self.buckets)
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        if self._hip:
+            # a gradient torch autograd produced itself (a parameter used by a torch op: variable embedding, torch/MIOpen decoder)
+            # is not in the flat buffer the buckets are slices of: move it there before its bucket can be reduced
+            slot = getattr(p, "_ucf_slot", None)
+            if slot is not None and p.grad is not None and slot[0].owns(p, slot[1]):
+                view = slot[0].grad_view(p, slot[1], slot[2])
+                if p.grad.data_ptr() != view.data_ptr() and p.grad.dtype == view.dtype:
+                    view.copy_(p.grad)
+                    p.grad = view
         b = self.param_bucket[p]
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:

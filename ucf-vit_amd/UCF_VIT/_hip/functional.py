@@ -589,6 +589,30 @@ class AdaptivePosFn(torch.autograd.Function):
         return gx, None, g_w, g_b, g_c, None
 
 
+class VarAggFn(torch.autograd.Function):
+    """The attention of VariableMapping_Attention (building_blocks.py:336-366) for one aggregated variable: kv rows ordered (v, r),
+    q = the projected learnt query [D] (fp32) -> [R, D]."""
+
+    @staticmethod
+    def forward(ctx, kv, q, V, head_dim, scale):
+        kv = kv if kv.is_contiguous() else kv.contiguous()
+        q32 = (q if q.dtype == torch.float32 else q.float()).reshape(-1).contiguous()
+        D = q32.numel()
+        R = kv.shape[0] // V
+        out, lse = ops.varagg_fwd(kv, q32, V, R, D, head_dim, scale)
+        ctx.save_for_backward(kv, q32, out, lse)
+        ctx.meta = (V, R, D, head_dim, scale, q.dtype, q.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        kv, q32, out, lse = ctx.saved_tensors
+        V, R, D, head_dim, scale, q_dtype, q_shape = ctx.meta
+        d = _as(dout, kv.dtype)
+        dkv, dq = ops.varagg_bwd(kv, q32, out, lse, d, V, R, D, head_dim, scale)
+        return dkv, dq.to(q_dtype).view(q_shape), None, None, None
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """nn.CrossEntropyLoss()(logits, labels), mean reduction (train_class_simple.py:24-30); fp32 loss scalar."""
 

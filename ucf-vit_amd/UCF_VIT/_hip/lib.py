@@ -54,6 +54,8 @@ SIGNATURES = {
     "ucfvit_tokens_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P]),
     "ucfvit_tokens_bwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
     "ucfvit_seq_patches": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "ucfvit_varagg_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
+    "ucfvit_varagg_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_quadtree_workspace": (_I64, [_I64, _I64, _I64]),
     "ucfvit_octree_workspace": (_I64, [_I64, _I64]),
     "ucfvit_octree_build": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P]),

@@ -349,6 +349,31 @@ def adaptive_pos_bwd(dout, seq_ps, w, bias, B, S, D, has_cls, want_dx=True, dw=N
     return dx, dw, dbias, (dcls if has_cls else None)
 
 
+# ------------------------------------------------------------------------------------------------ variable aggregation
+def varagg_fwd(kv, q, V, R, D, head_dim, scale):
+    """kv [V*R, 2D] (rows ordered (v, r)), q fp32 [D] -> (out [R, D], lse fp32 [R, H])"""
+    L = _l.load()
+    _chk(kv, "varagg.kv"), _chk(q, "varagg.q")
+    if tuple(kv.shape) != (V * R, 2 * D) or q.dtype != torch.float32 or q.numel() != D:
+        raise ValueError("varagg_fwd: kv must be [V*R, 2D] and q fp32 [D]")
+    out = torch.empty((R, D), dtype=kv.dtype, device=kv.device)
+    lse = torch.empty((R, D // head_dim), dtype=torch.float32, device=kv.device)
+    _l.check(L.ucfvit_varagg_fwd(kv.data_ptr(), q.data_ptr(), out.data_ptr(), lse.data_ptr(), R, V, D, head_dim, scale, dt(kv), _stream()),
+             "ucfvit_varagg_fwd")
+    return out, lse
+
+
+def varagg_bwd(kv, q, out, lse, dout, V, R, D, head_dim, scale):
+    """-> (dkv [V*R, 2D], dq fp32 [D])"""
+    L = _l.load()
+    _chk(dout, "varagg_bwd.dout")
+    dkv = torch.empty_like(kv)
+    dq_rows = torch.empty((R, D), dtype=torch.float32, device=kv.device)
+    _l.check(L.ucfvit_varagg_bwd(kv.data_ptr(), q.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dkv.data_ptr(), dq_rows.data_ptr(),
+                                 R, V, D, head_dim, scale, dt(kv), _stream()), "ucfvit_varagg_bwd")
+    return dkv, colsum(dq_rows)
+
+
 # ------------------------------------------------------------------------------------------------ quadtree patcher
 def quadtree_build(edges, fixed_length):
     """edges uint8 [B, H, W] (0 / 255) -> (nodes int32 [B, L, 4] = (x1, x2, y1, y2), values int32 [B, L], count int32 [B],

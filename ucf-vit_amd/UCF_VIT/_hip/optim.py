@@ -17,6 +17,19 @@ class HipAdamW(torch.optim.Optimizer):
         self.grad_scale = grad_scale  # multiplies gradients inside the kernel (e.g. 1/world_size, or 1/loss_scale)
 
     @staticmethod
+    def _adopt_foreign_grads(group):
+        """a gradient that torch autograd produced itself (a parameter used by a torch op: the variable embedding, a torch/MIOpen
+        decoder) lives outside the flat buffer: copy it into its slot and re-point p.grad, so the group keeps its one-launch update"""
+        for p in group["params"]:
+            s = getattr(p, "_ucf_slot", None)
+            if s is None or p.grad is None or not s[0].owns(p, s[1]):
+                continue
+            view = s[0].grad_view(p, s[1], s[2])
+            if p.grad.data_ptr() != view.data_ptr() and p.grad.dtype == view.dtype and p.grad.device == view.device:
+                view.copy_(p.grad)
+                p.grad = view
+
+    @staticmethod
     def _flat_run(group):
         """(store, start, end) if the group's params are one contiguous run of a store with grads in the flat buffer."""
         ps = group["params"]
@@ -45,6 +58,7 @@ class HipAdamW(torch.optim.Optimizer):
                 continue
             b1, b2 = group["betas"]
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            self._adopt_foreign_grads(group)
             run = self._flat_run(group)
             if run is not None:
                 st, lo, hi = run

@@ -240,14 +240,39 @@ class VIT(nn.Module):
 
     def _embed_tokens(self, x, variables):
         if self.use_varemb:
-            raise NotImplementedError("the use_varemb front end (per-variable embedding + variable aggregation) is a 'next' row "
-                                      "(SURVEY.md §8f); the HIP path covers use_varemb=False")
+            return self._embed_variables(x, variables)
         if self.adaptive_patching and not self.sqrt_len_method:
             # reference :465-467: x [B, C, S, P] arrives already cut into S resized patches -> rows (p c) -> LN, Linear, LN
             if x.dim() != 4 or x.shape[1] * x.shape[3] != self.patch_dim:
                 raise ValueError(f"adaptive_patching expects x [B, C={self.in_chans}, S, P={self.patch_dim_woc}], got {tuple(x.shape)}")
             return self.token_embeds(HF.SeqPatchesFn.apply(x, _cd(self)))
         return self.token_embeds(x)
+
+    def get_var_ids(self, variables):
+        return [self.var_map[v] for v in variables]
+
+    def _embed_variables(self, x, variables):
+        """use_varemb front end (reference :434-462): every input channel is tokenised on its own by the token embedding of ITS variable,
+        gets that variable's embedding and — unless there is a single channel — the V embeddings of a token are aggregated by the
+        cross-attention with the learnt query (aggregate_variables, :414-432).  The per-variable embeddings run on the HIP kernels;
+        stacking them (variable-major, so nothing is permuted) and adding the variable embedding are two element-wise torch ops."""
+        ids = self.get_var_ids(tuple(variables))
+        adaptive = self.adaptive_patching and not self.sqrt_len_method
+        if x.shape[1] < (1 if self.single_channel else len(ids)):
+            raise ValueError(f"use_varemb: {len(ids)} variables but input has {x.shape[1]} channels")
+        toks = []
+        for i, vid in enumerate(ids):
+            xi = x[:, i] if adaptive else x[:, i:i + 1]           # [B, S, P] pre-cut patches of this channel | a 1-channel image
+            toks.append(self.token_embeds[vid](xi))               # [B, L, D]
+            if self.single_channel:
+                break
+        ve = self.var_embed[0, ids[:len(toks)]].to(toks[0].dtype)  # [V, D]
+        if self.single_channel or self.var_agg is None:
+            return toks[0] + ve[0]
+        B, L, D = toks[0].shape
+        xs = torch.stack(toks, dim=0) + ve.view(-1, 1, 1, D)      # [V, B, L, D]
+        out = self.var_agg(self.var_query, xs.view(len(toks), B * L, D))
+        return out.view(B, L, D)
 
     def _pos_embed(self, x: torch.Tensor, seq_ps) -> torch.Tensor:
         if self.pos_embed is None:

@@ -285,8 +285,10 @@ class EmbeddingDenseLayer(nn.Module):
 
 
 class VariableMapping_Attention(nn.Module):
-    """Cross-attention that aggregates per-variable tokens (reference :301-373).  Parameter holder with the reference's
-    state_dict layout; the aggregation itself is a 'next' row and not on the HIP hot path yet."""
+    """Cross-attention that aggregates the per-variable tokens of every position with a learnt query (reference :301-373).
+    forward(var_query [1, N_a = 1, D], x [V, R, D]) -> [R, D]: the q / kv / proj Linears are MFMA GEMMs, the softmax over the V
+    variables and the weighted sum are one HBM-bound kernel (csrc/varagg.hip).  One aggregated variable (the reference's
+    `aggregated_variables = 1`); x is laid out variable-major instead of [R, V, D] so that no permuted copy is needed."""
 
     def __init__(self, dim: int, fused_attn: FusedAttn = FusedAttn.NONE, num_heads: int = 8, qkv_bias: bool = False,
                  qk_norm: bool = False, proj_bias: bool = True, attn_drop: float = 0.0, proj_drop: float = 0.0,
@@ -297,13 +299,22 @@ class VariableMapping_Attention(nn.Module):
         self.head_dim = dim // num_heads
         self.scale = self.head_dim ** -0.5
         self.fused_attn = fused_attn
-        self.q = nn.Linear(dim, dim, bias=qkv_bias)
-        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.q = Linear(dim, dim, bias=qkv_bias)
+        self.kv = Linear(dim, dim * 2, bias=qkv_bias)
         self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
         self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self.proj = Linear(dim, dim, bias=proj_bias)
         self.proj_drop = nn.Dropout(proj_drop)
+        self.qk_norm = qk_norm
 
     def forward(self, var_query: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("variable aggregation (use_varemb with several variables) is outside the round-1 HIP hot path")
+        if self.qk_norm or (self.training and (self.attn_drop.p > 0.0 or self.proj_drop.p > 0.0)):
+            raise NotImplementedError("qk_norm / dropout inside the variable aggregation are not on the HIP hot path")
+        if var_query.shape[1] != 1:
+            raise NotImplementedError("aggregated_variables > 1 is not on the HIP hot path")
+        V, R, D = x.shape
+        q = self.q(var_query.reshape(1, D))                       # [1, D], the same query for every token
+        kv = self.kv(x.reshape(V * R, D))                         # [V * R, 2 D]
+        out = HF.VarAggFn.apply(kv, q, V, self.head_dim, self.scale)
+        return self.proj(out)
