@@ -584,6 +584,22 @@ def test_train_scripts_run_the_adaptive_patching_configuration(tmp_path):
     assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and losses[1] < losses[0], out
 
 
+def test_train_class_script_runs_variable_aggregation(tmp_path):
+    """use_varemb: True in the reference-schema config: three channels tokenised separately and aggregated, on token sequences from
+    the GPU patcher; bf16"""
+    cfg = _smoke_cfg()
+    cfg["trainer"]["data_type"] = "bfloat16"
+    a = cfg["model"]["net"]["init_args"]
+    a.update(tile_size=[64, 64], patch_size=8, embed_dim=128, depth=2, num_heads=2, adaptive_patching=True, fixed_length=49, use_adaptive_pos_emb=True,
+             use_varemb=True)
+    cfg["model"]["lr"] = 1e-3
+    cfg["model"]["warmup_steps"] = 2
+    cfg["load_balancing"]["batches_per_rank_epoch"]["catsdogs"] = 6
+    out = _run_entry("train_class_simple.py", cfg, tmp_path, 29584)
+    losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses), out
+
+
 def test_train_sap_and_unetr_scripts_run_adaptive_configs(tmp_path):
     """basic_ct/sap and basic_ct/unetr set adaptive_patching + use_adaptive_pos_emb: SAP on 2-D pseudo images (fixed_length 16 = 3n+1
     and a square), UNETR on 3-D pseudo volumes (fixed_length 8 = 7n+1 and a cube) with the full volume feeding the first conv encoder"""

@@ -43,12 +43,10 @@ def model_args(conf):
     a, d = conf["model"]["net"]["init_args"], conf["data"]
     dataset = d["dataset"]
     chans = 1 if d.get("single_channel", False) else max(1, d["num_channels_used"][dataset])
-    if a.get("use_varemb", False):
-        raise NotImplementedError("use_varemb configs are a 'next' row (SURVEY.md §8f); set it False")
     adaptive = bool(a.get("adaptive_patching", False))
     return dict(img_size=a["tile_size"], patch_size=a["patch_size"], in_chans=chans, embed_dim=a["embed_dim"], depth=a["depth"],
                 num_heads=a["num_heads"], mlp_ratio=a["mlp_ratio"], drop_path_rate=a.get("drop_path", 0.0), twoD=a["twoD"],
-                default_vars=a["default_vars"], single_channel=d.get("single_channel", False), use_varemb=False,
+                default_vars=a["default_vars"], single_channel=d.get("single_channel", False), use_varemb=bool(a.get("use_varemb", False)),
                 adaptive_patching=adaptive, fixed_length=a.get("fixed_length", 4096),
                 use_adaptive_pos_emb=bool(a.get("use_adaptive_pos_emb", False)) and adaptive), a, d
 
