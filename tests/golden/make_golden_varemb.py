@@ -19,7 +19,7 @@ import _ref_standins  # noqa: E402
 _ref_standins.install()
 from det_weights import det_state_dict, det_tensor  # noqa: E402
 
-from UCF_VIT.simple.arch import VIT  # noqa: E402  (reference)
+from UCF_VIT.simple.arch import MAE, VIT  # noqa: E402  (reference)
 from UCF_VIT.utils.fused_attn import FusedAttn  # noqa: E402
 
 torch.set_num_threads(4)
@@ -55,4 +55,31 @@ kw = dict(img_size=[32, 32], patch_size=8, in_chans=3, num_classes=5, embed_dim=
           FusedAttn_option=FusedAttn.NONE)
 case("model_vit_varemb.npz", kw, det_tensor((B, 3, S, 64), 80), ["v", "q", "u"], seq_ps, 81)     # 3 of the 4 variables, out of order
 case("model_vit_varemb_single.npz", dict(kw, in_chans=1, single_channel=True), det_tensor((B, 1, S, 64), 82), ["t"], seq_ps, 83)
+
+
+def mae_case(name, kw, x, variables, seq_ps, noise, seed):
+    model = MAE(**kw)
+    model.load_state_dict(det_state_dict(model, seed, keep=()))
+    model.train()
+    orig = model.random_masking
+    model.random_masking = lambda s_, noise_=None: orig(s_, noise)
+    pred, mask = model(x, variables, seq_ps)
+    # the reference's adaptive MAE target (train_masked_simple.py:29) has in_chans * p^2 entries per token like the prediction
+    target = x.permute(0, 2, 3, 1).flatten(2)
+    loss = torch.nn.MSELoss()(pred, target)
+    loss.backward()
+    rec = dict(x=x, seq_ps=seq_ps, noise=noise, pred=pred, mask=mask, loss=loss)
+    for k, p in model.named_parameters():
+        rec["g." + k] = p.grad if p.grad is not None else torch.zeros_like(p)
+    out_np = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in rec.items()}
+    np.savez_compressed(os.path.join(HERE, name), **out_np)
+    print(name, variables, {k: v.shape for k, v in out_np.items() if not k.startswith("g.")}, loss.item())
+
+
+mae_kw = dict(img_size=[32, 32], patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True, fixed_length=S,
+              class_token=False, weight_init='skip', mask_ratio=0.5, linear_decoder=False, decoder_depth=1, decoder_embed_dim=32,
+              decoder_num_heads=1, mlp_ratio_decoder=4.0, use_varemb=True, default_vars=DEFAULT_VARS, single_channel=False,
+              use_adaptive_pos_emb=True, FusedAttn_option=FusedAttn.NONE)
+noise = torch.from_numpy(np.random.Generator(np.random.PCG64(85)).random((B, S)).astype(np.float32))
+mae_case("model_mae_varemb.npz", mae_kw, det_tensor((B, 3, S, 64), 86), ["q", "u", "t"], seq_ps, noise, 87)
 print("done")

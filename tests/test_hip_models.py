@@ -222,6 +222,30 @@ def test_vit_variable_aggregation_vs_reference(name, single, variables, seed, ch
     _check_grads_vs_golden(m, g, tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_mae_variable_aggregation_vs_reference(dtype, tol):
+    """MAE(use_varemb=True) on adaptively patched input (the same front end through MAE.forward_features, arch.py:704-745): prediction,
+    bit-exact mask, loss against the rearranged sequence, every gradient; fixture generated from the reference"""
+    from UCF_VIT.simple.arch import MAE
+    from UCF_VIT.utils.metrics import seq_mse_loss
+    g = load_golden("model_mae_varemb.npz")
+    m = MAE(img_size=[32, 32], patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2, adaptive_patching=True, fixed_length=12,
+            class_token=False, weight_init='skip', mask_ratio=0.5, linear_decoder=False, decoder_depth=1, decoder_embed_dim=32,
+            decoder_num_heads=1, mlp_ratio_decoder=4.0, use_varemb=True, default_vars=["u", "v", "t", "q"], single_channel=False,
+            use_adaptive_pos_emb=True)
+    m.load_state_dict(det_state_dict(m, 87, keep=()))
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    x = g["x"].to(DEV)
+    pred, mask = m(x, ["q", "u", "t"], g["seq_ps"].to(DEV), noise=g["noise"].to(DEV))
+    assert torch.equal(mask.cpu(), g["mask"])
+    loss = seq_mse_loss(pred, x)
+    loss.backward()
+    assert rel_err(pred.float(), g["pred"]) < tol
+    assert abs(loss.item() - g["loss"].item()) < tol * max(1.0, abs(g["loss"].item()))
+    _check_grads_vs_golden(m, g, tol)
+
+
 def test_vit_adaptive_patching_trains_like_the_oracle():
     """10 AdamW steps on one adaptive batch (bf16 HIP path against the fp32 CPU oracle): same loss curve, loss goes down"""
     from oracle import ucf_vit_ref as R
