@@ -53,3 +53,29 @@ def test_error_reporting_without_gpu():
     assert rc == -1 and b"null descriptor" in L.ucfvit_last_error()
     rc = L.ucfvit_attention_fwd(1, 1, 1, 1, 1, 1, 48, ctypes.c_float(1.0), 0, None)
     assert rc == -1 and b"head dim" in L.ucfvit_last_error()
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    """the newest committed bench line (profiles/r01_*_bench_vitl16_b166.json, written by `python bench.py` on an MI355X) carries every
+    key of the driver's contract plus the roofline / cpu_baseline objects, with consistent arithmetic"""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_vitl16_b166.json")))
+    assert files, "no committed bench line"
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(d["value"] - d["config"]["global_batch"] * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
