@@ -2,20 +2,31 @@
 """Benchmark of the ViT training hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                      (starts N ranks itself, one per GPU, over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = forward + cross-entropy + backward (+ data-parallel gradient all-reduce) + fused AdamW + zero_grad +
-scheduler step on one synthetic batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
+One "step" = forward + loss + backward (+ data-parallel gradient all-reduce) + fused AdamW + zero_grad + scheduler step on one
+synthetic batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
 
-metric : images/sec (whole job) for ViT-L/16 224^2, bf16 compute with fp32 master weights (BASELINE.json).
-roofline: the dominant kernel is the bf16 MFMA GEMM (gemm3_kernel<...>, csrc/gemm2.hip); `achieved` = algorithmic FLOPs of all
-          GEMM launches in the timed region (forward, data gradient, grouped weight gradient) / their HIP-event-measured
-          durations (events recorded on the launch stream).
+workloads (BASELINE.json configs):
+  vit_l16_224            headline: ViT-L/16 224^2 classification step (train_class_simple.py:344-357), configs[2]
+  vit_b16_224            configs[1]
+  mae_vit_l16_224        configs[3]: MAE ViT-L/16 mask ratio 0.75, decoder 8 x 512 / 16 heads, MSE over all patches
+                         (train_masked_simple.py:35-49, configs/imagenet/mae/base_config.yaml:44-46)
+  unetr_enc_512x512x128  configs[4], encoder: 512x512x128 volumes, p 16 -> 8192 tokens, D 768 / 12 / 12, taps after blocks 3, 6, 9
+                         (simple/arch.py:995-1086); synthetic quadratic objective on the taps + features (the conv decoder and the
+                         Dice/CE loss are SURVEY §8f row 2, outside this figure: BASELINE.md §4 "conv decoder excluded")
+roofline: the dominant kernel family of the workload — the bf16 MFMA GEMM (gemm3_kernel, csrc/gemm2.hip) for the 224^2 workloads, the
+          streaming attention kernels (csrc/attention.hip) for the 8192-token encoder; `achieved` = algorithmic FLOPs of that family's
+          launches in the timed region / their HIP-event-measured durations (events recorded on the launch stream).
 cpu_baseline: the CPU oracle's training loop (oracle/ucf_vit_ref.py, kind "port") on this box's host cores, rank 0, N=1 only.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,95 +35,163 @@ for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 WORKLOADS = {
-    # name: (img, patch, dim, depth, heads, classes, default per-GPU batch)
-    "vit_l16_224": dict(img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166),   # 166*197 = 32702 rows -> 128 M-tiles of 256: every GEMM fills whole rounds of 256 CUs
-    "vit_b16_224": dict(img=224, patch=16, dim=768, depth=12, heads=12, classes=1000, batch=332),   # 65404 rows -> 256 M-tiles: 3 N-tiles of 256 fill whole rounds
-    "vit_tiny16_256": dict(img=256, patch=16, dim=192, depth=12, heads=3, classes=2, batch=256),
+    # 166*197 = 32702 rows -> 128 M-tiles of 256: every GEMM fills whole rounds of 256 CUs
+    "vit_l16_224": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166),
+    "vit_b16_224": dict(kind="vit", img=224, patch=16, dim=768, depth=12, heads=12, classes=1000, batch=332),   # 65404 rows -> 256 M-tiles
+    "vit_tiny16_256": dict(kind="vit", img=256, patch=16, dim=192, depth=12, heads=3, classes=2, batch=256),
     # SURVEY §8f row 1 (not the headline metric): the reference's imagenet config shape, adaptive_patching with fixed_length 196 and
     # use_adaptive_pos_emb (configs/imagenet/classification/base_config.yaml:46-49); input = token sequences [B, 3, 196, 256] + seq_ps
-    "vit_l16_adaptive196": dict(img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166, adaptive=196),
+    "vit_l16_adaptive196": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166, adaptive=196),
+    # 256 * 49 = 12544 encoder rows = 49 M-tiles, 256 * 196 = 50176 decoder rows = 196 M-tiles
+    "mae_vit_l16_224": dict(kind="mae", img=224, patch=16, dim=1024, depth=24, heads=16, batch=256, mask_ratio=0.75,
+                            dec_dim=512, dec_depth=8, dec_heads=16),
+    # per-GPU batch 2 = the reference's basic_ct batch size (configs/basic_ct/unetr/base_config.yaml:82)
+    "unetr_enc_512x512x128": dict(kind="unetr", vol=(512, 512, 128), patch=16, dim=768, depth=12, heads=12, batch=2),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
 
 
-def train_flops_per_image(w):
-    """algorithmic FLOPs of one training step per image = 3 x forward"""
-    n = (w["img"] // w["patch"]) ** 2 + 1
-    d = w["dim"]
-    layer = 24 * n * d * d + 4 * n * n * d
-    patch = 2 * (n - 1) * (3 * w["patch"] ** 2) * d
-    head = 2 * d * w["classes"]
-    return 3 * (w["depth"] * layer + patch + head)
+def _layer_flops(n, d):
+    return 24 * n * d * d + 4 * n * n * d
 
 
-class GemmProfiler:
-    """HIP-event timing of every ucfvit_gemm / ucfvit_gemm_grouped launch in the timed region (events on the launch stream)."""
+def train_flops_per_unit(w):
+    """algorithmic FLOPs of one training step per image / volume = 3 x forward"""
+    if w["kind"] == "vit":
+        n = (w["img"] // w["patch"]) ** 2 + 1
+        d = w["dim"]
+        patch = 2 * (n - 1) * (3 * w["patch"] ** 2) * d
+        return 3 * (w["depth"] * _layer_flops(n, d) + patch + 2 * d * w["classes"])
+    if w["kind"] == "mae":
+        L = (w["img"] // w["patch"]) ** 2
+        keep = int(L * (1 - w["mask_ratio"]))
+        d, dd, P = w["dim"], w["dec_dim"], 3 * w["patch"] ** 2
+        fwd = (w["depth"] * _layer_flops(keep, d) + 2 * L * P * d + 2 * keep * d * dd + w["dec_depth"] * _layer_flops(L, dd) + 2 * L * dd * P)
+        return 3 * fwd
+    n = 1
+    for s in w["vol"]:
+        n *= s // w["patch"]
+    return 3 * (w["depth"] * _layer_flops(n, w["dim"]) + 2 * n * w["patch"] ** 3 * w["dim"])
+
+
+def source_hash():
+    """hash of the kernel sources + C ABI header of the running build: a committed PMC profile counts only for the code it measured"""
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "ucfvit_hip.h")]
+    cs = os.path.join(ROOT, "ucf-vit_amd", "csrc")
+    files += sorted(os.path.join(cs, f) for f in os.listdir(cs) if f.endswith((".hip", ".h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, dtype, batch, family, profiles_dir=None):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes of this same command (separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction: tools/pmc_summarize.py) — counters cannot be read from inside the
+    process.  A profile is used only if it was taken from THIS build: its recorded `src_hash` must equal the hash of the kernel
+    sources now in the tree; otherwise (stale or no profile) the figure is null and `traffic_note` says why."""
+    import glob
+    want = source_hash()
+    note = "no committed PMC profile for this workload"
+    for f in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*pmc_traffic*.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        if d.get("workload") != workload or d.get("dtype") != dtype or d.get("per_gpu_batch") != batch:
+            continue
+        if d.get("src_hash") != want:
+            note = f"stale: {os.path.basename(f)} measured source {d.get('src_hash')}, this build is {want}"
+            continue
+        ent = d.get("families", {}).get(family)
+        if ent:
+            return round(ent["hbm_bytes_per_launch_corrected"]), os.path.basename(f)
+    return None, note
+
+
+# --------------------------------------------------------------------------------------------------------------- parent: start N ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, like
+    torch.distributed.run does) BEFORE this process has touched the GPU, wait for all, relay rank 0's JSON line.  The parent never
+    initialises HIP and never replaces itself (children are ordinary subprocesses)."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))   # stderr of every rank is inherited
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+
+
+# --------------------------------------------------------------------------------------------------------------- in-process profiler
+class KernelProfiler:
+    """HIP-event timing of the launches of the two MFMA kernel families in the timed region (events on the launch stream = torch's
+    current stream): `gemm` = every ucfvit_gemm / ucfvit_gemm_grouped call, `attention` = every ucfvit_attention_fwd / _bwd call."""
 
     def __init__(self):
-        self.records = []   # (start_evt, end_evt, flops, is_mfma_path)
+        self.records = {"gemm": [], "attention": []}   # (start_evt, end_evt, algorithmic flops)
         self.enabled = False
+
+    def _timed(self, family, fn, flops_of):
+        import torch
+        prof = self
+
+        def wrapper(*a, **kw):
+            if not prof.enabled:
+                return fn(*a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **kw)
+            e.record()
+            prof.records[family].append((s, e, flops_of(*a, **kw)))
+            return out
+        return wrapper
 
     def install(self):
         from UCF_VIT._hip import ops
-        orig = ops.gemm
-        prof = self
+        ops.gemm = self._timed("gemm", ops.gemm, lambda A, B, M, N, K, *a, **kw: 2.0 * M * N * K)
+        ops.wgrad_grouped = self._timed("gemm", ops.wgrad_grouped,
+                                        lambda items: sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items))
+        # algorithmic attention FLOPs: forward 4 B H N^2 dh (QK^T and PV), backward twice that (train = 3 x forward, SURVEY §8d);
+        # the recompute of S and dP inside the backward kernels is not credited
+        ops.attention_fwd = self._timed("attention", ops.attention_fwd, lambda qkv, B, N, H, dh, scale: 4.0 * B * H * N * N * dh)
+        ops.attention_bwd = self._timed("attention", ops.attention_bwd,
+                                        lambda qkv, out, dout, lse, B, N, H, dh, scale: 8.0 * B * H * N * N * dh)
 
-        def timed_gemm(A, B, M, N, K, *a, **kw):
-            if not prof.enabled:
-                return orig(A, B, M, N, K, *a, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = orig(A, B, M, N, K, *a, **kw)
-            e.record()
-            prof.records.append((s, e, 2.0 * M * N * K))
-            return out
-        ops.gemm = timed_gemm
-        orig_grouped = ops.wgrad_grouped
-
-        def timed_grouped(items):
-            if not prof.enabled:
-                return orig_grouped(items)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = orig_grouped(items)
-            e.record()
-            prof.records.append((s, e, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)))
-            return out
-        ops.wgrad_grouped = timed_grouped
-
-    def summary(self):
+    def summary(self, family):
         tot_ms, tot_flops = 0.0, 0.0
-        for s, e, f in self.records:
+        for s, e, f in self.records[family]:
             tot_ms += s.elapsed_time(e)
             tot_flops += f
-        n = len(self.records)
-        return n, tot_ms, tot_flops
+        return len(self.records[family]), tot_ms, tot_flops
 
 
-def pmc_traffic(workload, dtype, batch):
-    """HBM bytes per launch of the dominant kernel (average over every gemm3_kernel launch of the step) from the committed rocprofv3
-    PMC passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, newest profiles/*pmc_traffic*.json whose
-    workload / dtype / batch match) — counters cannot be read from inside the process; null if no matching profile."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-            if d.get("workload") == workload and d.get("dtype") == dtype and d.get("per_gpu_batch") == batch:
-                k = d["kernels"]
-                if "ALL gemm3_kernel launches" in k:
-                    return round(k["ALL gemm3_kernel launches"]["hbm_bytes_per_launch_corrected"])
-        except Exception:
-            pass
-    return None
-
-
-def cpu_baseline(wname, w, steps=3, batch=8):
-    """reference training loop (train_class_simple.py:344-357) restated on CPU fp32: oracle, timed on the host cores"""
+# --------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(wname, w, steps=5):
+    """reference training loop (train_class_simple.py:344-357 / train_masked_simple.py:35-49) restated on CPU fp32: the oracle, timed
+    on the host cores; >= 3 warm-up-equivalent (1 untimed step that also sizes the leg) + 5 timed steps when they fit ~30 s"""
+    import torch
     from oracle import ucf_vit_ref as R
     try:
         cores = len(os.sched_getaffinity(0))
@@ -122,25 +201,182 @@ def cpu_baseline(wname, w, steps=3, batch=8):
     torch.set_num_threads(cores)
     if w.get("adaptive"):
         return None          # the headline baseline is the image-input loop; the adaptive oracle is timed by nothing
-    m = R.VIT([w["img"], w["img"]], patch_size=w["patch"], in_chans=3, num_classes=w["classes"], embed_dim=w["dim"], depth=w["depth"],
-              num_heads=w["heads"], sdpa=True)
-    opt = R.configure_optimizer(m, 1e-4, 0.9, 0.95, 1e-5)
-    sch = R.WarmupCosineLR(opt, 1000, 20000, 1e-8, 1e-8)
     g = torch.Generator().manual_seed(0)
-    x = torch.randint(0, 256, (batch, 3, w["img"], w["img"]), generator=g).float()
-    y = torch.randint(0, w["classes"], (batch,), generator=g)
+    if w["kind"] == "vit":
+        batch, unit = 8, "images/sec"
+        m = R.VIT([w["img"], w["img"]], patch_size=w["patch"], in_chans=3, num_classes=w["classes"], embed_dim=w["dim"], depth=w["depth"],
+                  num_heads=w["heads"], sdpa=True)
+        x = torch.randint(0, 256, (batch, 3, w["img"], w["img"]), generator=g).float()
+        y = torch.randint(0, w["classes"], (batch,), generator=g)
+        opt = R.configure_optimizer(m, 1e-4, 0.9, 0.95, 1e-5)
+        sch = R.WarmupCosineLR(opt, 1000, 20000, 1e-8, 1e-8)
+        what = f"{wname} fp32 CPU oracle train step, batch {batch}"
+
+        def one():
+            R.train_step_class(m, opt, sch, x, y)
+    elif w["kind"] == "mae":
+        batch, unit = 8, "images/sec"
+        m = R.MAE([w["img"], w["img"]], patch_size=w["patch"], in_chans=3, num_classes=None, embed_dim=w["dim"], depth=w["depth"],
+                  num_heads=w["heads"], class_token=False, mask_ratio=w["mask_ratio"], decoder_depth=w["dec_depth"],
+                  decoder_embed_dim=w["dec_dim"], decoder_num_heads=w["dec_heads"], sdpa=True)
+        x = torch.rand(batch, 3, w["img"], w["img"], generator=g)
+        opt = R.configure_optimizer(m, 1e-4, 0.9, 0.95, 0.05)
+        sch = R.WarmupCosineLR(opt, 1000, 20000, 1e-8, 1e-8)
+        what = f"{wname} fp32 CPU oracle MAE train step (MSE over all patches), batch {batch}"
+
+        def one():
+            R.train_step_mae(m, opt, sch, x)
+    else:
+        # bounded sample of the volume workload: ONE 128 x 128 x 128 crop (512 tokens) of the same encoder and objective; the 8192-token
+        # volume would take minutes per step on the host (attention cost grows with N^2, so the per-volume rate is extrapolated by
+        # FLOPs in `sample`, not by voxels)
+        batch, unit = 1, "volumes/sec"
+        crop = (128, 128, 128)
+        m = R.VIT(list(crop), patch_size=w["patch"], in_chans=1, num_classes=None, embed_dim=w["dim"], depth=w["depth"], num_heads=w["heads"],
+                  class_token=False, twoD=False, sdpa=True)
+        x = torch.rand(batch, 1, *crop, generator=g)
+        opt = R.configure_optimizer(m, 1e-4, 0.9, 0.95, 1e-5)
+        sch = R.WarmupCosineLR(opt, 1000, 20000, 1e-8, 1e-8)
+        taps_at = [(i + 1) * (w["depth"] // 4) for i in range(3)]
+        crop_w = dict(w, vol=crop)
+        scale = train_flops_per_unit(crop_w) / train_flops_per_unit(w)
+        what = (f"{wname} fp32 CPU oracle encoder step on a 128^3 crop (512 tokens), scaled to whole volumes by algorithmic FLOPs "
+                f"(x{scale:.5f})")
+
+        def one():
+            feats, taps = R.vit_forward_intermediates(m, x, taps_at)
+            loss = feats.square().mean() + sum(t.square().mean() for t in taps)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            sch.step()
     t0 = time.perf_counter()
-    R.train_step_class(m, opt, sch, x, y)     # warm-up
+    one()     # warm-up
     warm = time.perf_counter() - t0
     print(f"[bench] cpu_baseline warm-up step {warm:.1f} s on {cores} threads", file=sys.stderr, flush=True)
-    steps = max(1, min(steps, int(25.0 / max(warm, 1e-3))))     # keep the whole leg to ~10-30 s of CPU work
+    steps = max(1, min(steps, int(30.0 / max(warm, 1e-3))))     # keep the whole leg to ~10-30 s of CPU work
     t0 = time.perf_counter()
     for i in range(steps):
-        R.train_step_class(m, opt, sch, x, y)
+        one()
         print(f"[bench] cpu_baseline step {i + 1}/{steps}", file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{wname} fp32 CPU oracle train step, batch {batch}, {steps} timed steps after 1 warm-up ({dt:.1f} s)"}
+    value = batch * steps / dt
+    if w["kind"] == "unetr":
+        value *= scale
+    return {"value": value, "unit": unit, "cores": cores, "kind": "port", "sample": f"{what}, {steps} timed steps after 1 warm-up ({dt:.1f} s)"}
+
+
+# --------------------------------------------------------------------------------------------------------------- workloads
+def build_workload(args, w, dev, rank):
+    """-> (net-able model, step closure factory inputs): returns (model, make_step) where make_step(net, opt, sch) -> step()"""
+    import torch
+    from UCF_VIT.utils.fused_attn import FusedAttn
+    B = args.batch or w["batch"]
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)      # per-rank synthetic shard
+    variables = ["red", "green", "blue"]
+    if w["kind"] == "vit":
+        from UCF_VIT.simple.arch import VIT
+        from UCF_VIT.utils.metrics import cross_entropy_loss
+        adaptive = w.get("adaptive", 0)
+        akw = dict(adaptive_patching=True, fixed_length=adaptive, use_adaptive_pos_emb=True) if adaptive else {}
+        model = VIT(img_size=[w["img"], w["img"]], patch_size=w["patch"], in_chans=3, num_classes=w["classes"], embed_dim=w["dim"],
+                    depth=w["depth"], num_heads=w["heads"], mlp_ratio=4.0, FusedAttn_option=FusedAttn.HIP, **akw).to(dev)
+        seq_ps = None
+        if adaptive:     # pre-cut, resized patches as the reference's quadtree dataloader emits them, (size, x, y) per token
+            x = torch.randint(0, 256, (B, 3, adaptive, w["patch"] ** 2), generator=g).float().to(dev)
+            seq_ps = torch.cat([2.0 ** torch.randint(2, 7, (B, adaptive, 1), generator=g).float(),
+                                torch.randint(0, w["img"], (B, adaptive, 2), generator=g).float()], dim=-1).to(dev)
+        else:
+            x = torch.randint(0, 256, (B, 3, w["img"], w["img"]), generator=g).float().to(dev)   # un-normalised pixels, resident in HBM
+        y = torch.randint(0, w["classes"], (B,), generator=g).to(dev)
+
+        def make_step(net, opt, sch):
+            def step():
+                loss = cross_entropy_loss(net(x, variables, seq_ps), y)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                sch.step()
+                return loss
+            return step
+        desc = "train step (fwd+bwd+AdamW), synthetic U{0..255} images resident in HBM"
+        return model, make_step, B, desc, 1e-5
+    if w["kind"] == "mae":
+        from UCF_VIT.simple.arch import MAE
+        from UCF_VIT.utils.metrics import patch_mse_loss
+        model = MAE(img_size=[w["img"], w["img"]], patch_size=w["patch"], in_chans=3, embed_dim=w["dim"], depth=w["depth"],
+                    num_heads=w["heads"], class_token=False, weight_init='skip', mask_ratio=w["mask_ratio"], linear_decoder=False,
+                    decoder_depth=w["dec_depth"], decoder_embed_dim=w["dec_dim"], decoder_num_heads=w["dec_heads"], mlp_ratio_decoder=4.0,
+                    FusedAttn_option=FusedAttn.HIP).to(dev)
+        x = torch.rand(B, 3, w["img"], w["img"], generator=g).to(dev)         # min-max normalised images (dataloaders/dataset.py:76)
+        L = (w["img"] // w["patch"]) ** 2
+        noise = torch.rand(B, L, generator=g).to(dev)                          # fresh mask noise would be torch.rand on the device: same cost
+
+        def make_step(net, opt, sch):
+            def step():
+                pred, mask = net(x, variables, None, noise=noise)
+                loss = patch_mse_loss(pred, x, w["patch"])                     # loss_fn "MSE": over ALL patches (base_config.yaml:29)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                sch.step()
+                return loss
+            return step
+        desc = "MAE train step (mask 0.75 + gather, 24-block encoder on 49 tokens, 8 x 512 decoder on 196, MSE; fwd+bwd+AdamW), synthetic images resident in HBM"
+        return model, make_step, B, desc, 0.05
+    from UCF_VIT.simple.arch import UNETR
+    vol = list(w["vol"])
+    model = UNETR(img_size=vol, patch_size=w["patch"], in_chans=1, embed_dim=w["dim"], depth=w["depth"], num_heads=w["heads"],
+                  class_token=False, twoD=False, num_classes=4, linear_decoder=False, feature_size=16, skip_connection=True,
+                  FusedAttn_option=FusedAttn.HIP)
+    for n_, p_ in model.named_parameters():        # encoder workload: the conv decoder (MIOpen today, SURVEY §8f row 2) takes no part
+        if not n_.startswith(("blocks.", "patch_embed.", "token_embeds.", "norm.", "pos_embed")):
+            p_.requires_grad_(False)
+    model = model.to(dev)
+    x = torch.rand(B, 1, *vol, generator=g).to(dev)                            # basic_ct volumes are min-max normalised
+    taps_at = model.skip_indices
+
+    def make_step(net, opt, sch):
+        mod = net.module if hasattr(net, "module") else net
+
+        def step():
+            feats, taps = mod.forward_intermediates(x, None, None, indices=taps_at)
+            # synthetic objective on what the decoder consumes (final features + the three taps): four tiny element-wise reductions
+            loss = feats.float().square().mean() + sum(t.float().square().mean() for t in taps)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            sch.step()
+            return loss
+        return step
+    desc = "UNETR encoder train step (3-D patch embedding, 12 Blocks on 8192 tokens, taps 3/6/9; fwd+bwd+AdamW), synthetic volumes resident in HBM"
+    return model, make_step, B, desc, 1e-5
+
+
+def dry_run(args, world, rank):
+    """UCFVIT_BENCH_DRY=1 (tests on a box without a GPU): everything of the N-rank protocol except the GPU work — rendezvous over gloo,
+    the barrier-bracketed timed region, MAX over ranks, one JSON line from rank 0.  The line is marked "dry_run" and has no value."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "none (launcher rehearsal)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(args.steps, 1), 3), "workload": args.workload}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -152,15 +388,21 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload default)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])      # nothing below has run: this process has not touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU (or let bench.py start them: no WORLD_SIZE)")
+
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("UCFVIT_BENCH_DRY"):
+        return dry_run(args, world, rank)
     # Rehearsal switches (never set by the driver): UCFVIT_BENCH_BACKEND=gloo + UCFVIT_BENCH_ONE_GPU=1 run the N > 1 code path with
     # every rank on GPU 0 and host-staged gradient reduction, because RCCL refuses two ranks on one device (1-GPU development box).
     backend = os.environ.get("UCFVIT_BENCH_BACKEND", "nccl")
@@ -174,50 +416,25 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from UCF_VIT.simple.arch import VIT
-    from UCF_VIT.utils.fused_attn import FusedAttn
-    from UCF_VIT.utils.metrics import cross_entropy_loss
     from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
     from UCF_VIT._hip import lib
     lib.load()   # fail loudly if the HIP library is missing
 
     w = WORKLOADS[args.workload]
-    B = args.batch or w["batch"]
     cdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    adaptive = w.get("adaptive", 0)
-    akw = dict(adaptive_patching=True, fixed_length=adaptive, use_adaptive_pos_emb=True) if adaptive else {}
-    model = VIT(img_size=[w["img"], w["img"]], patch_size=w["patch"], in_chans=3, num_classes=w["classes"], embed_dim=w["dim"],
-                depth=w["depth"], num_heads=w["heads"], mlp_ratio=4.0, FusedAttn_option=FusedAttn.HIP, **akw).to(dev)
+    model, make_step, B, desc, wd = build_workload(args, w, dev, rank)
     model.set_compute_dtype(cdtype)
     net = model
     if world > 1:
         from UCF_VIT._hip.ddp import HipDataParallel
         net = HipDataParallel(model)
-    opt = configure_optimizer(model, 1e-4, 0.9, 0.95, 1e-5)        # configs/*/base_config.yaml: lr, betas, wd
+    opt = configure_optimizer(model, 1e-4, 0.9, 0.95, wd)        # configs/*/base_config.yaml: lr, betas, wd
     sch = configure_scheduler(opt, 1000, 20000, 1e-8, 1e-8)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)      # per-rank synthetic shard
-    seq_ps = None
-    if adaptive:     # pre-cut, resized patches as the reference's quadtree dataloader emits them, (size, x, y) per token
-        x = torch.randint(0, 256, (B, 3, adaptive, w["patch"] ** 2), generator=g).float().to(dev)
-        seq_ps = torch.cat([2.0 ** torch.randint(2, 7, (B, adaptive, 1), generator=g).float(),
-                            torch.randint(0, w["img"], (B, adaptive, 2), generator=g).float()], dim=-1).to(dev)
-    else:
-        x = torch.randint(0, 256, (B, 3, w["img"], w["img"]), generator=g).float().to(dev)   # un-normalised pixels, resident in HBM
-    y = torch.randint(0, w["classes"], (B,), generator=g).to(dev)
-    variables = ["red", "green", "blue"]
+    step = make_step(net, opt, sch)
 
-    prof = GemmProfiler()
+    prof = KernelProfiler()
     prof.install()
-
-    def step():
-        out = net(x, variables, seq_ps)
-        loss = cross_entropy_loss(out, y)
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-        sch.step()
-        return loss
 
     def log(msg):
         if rank == 0:
@@ -268,33 +485,49 @@ def main():
         mfma_stream = fl / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
     if rank == 0:
-        imgs = world * B * args.steps
-        value = imgs / dt
-        n_g, g_ms, g_flops = prof.summary()
+        units = world * B * args.steps
+        value = units / dt
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        achieved = (g_flops / (g_ms * 1e-3)) / 1e12 if g_ms > 0 else 0.0
-        step_tflops = value / world * train_flops_per_image(w) / 1e12
+        fam = {}
+        for name in ("gemm", "attention"):
+            n_l, ms, fl = prof.summary(name)
+            fam[name] = dict(launches=n_l, ms=ms, flops=fl, tflops=(fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0, share=ms * 1e-3 / dt)
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        other = "attention" if dom == "gemm" else "gemm"
+        kernel_names = {
+            "gemm": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
+                    "weight-gradient launch of the timed region)" % args.dtype,
+            "attention": "fused attention kernels (attn_fwd / attn_bwd_dq / attn_bwd_dkv streaming for N > 208, attn_s3_fwd / attn_g_bwd "
+                         "resident below): every forward and backward launch of the timed region, algorithmic FLOPs 4 / 8 B H N^2 dh",
+        }
+        step_tflops = value / world * train_flops_per_unit(w) / 1e12
+        traffic, traffic_src = pmc_traffic(args.workload, args.dtype, B, dom)
+        d = fam[dom]
+        unit = "volumes/sec" if w["kind"] == "unetr" else "images/sec"
+        headline = args.workload == "vit_l16_224" and args.dtype == "bf16"
         res = {
-            "metric": "images/sec/node ViT-L/16 224^2 bf16 train step" if args.workload == "vit_l16_224" and args.dtype == "bf16"
-            else f"images/sec/node {args.workload} {args.dtype} train step",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "images/sec/node ViT-L/16 224^2 bf16 train step" if headline else f"{unit.replace('/sec', '')}/sec/node {args.workload} {args.dtype} train step",
+            "value": round(value, 3 if w["kind"] == "unetr" else 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload} train step (fwd+bwd+AdamW), synthetic U{{0..255}} images resident in HBM",
+            "config": {"workload": f"{args.workload} {desc}",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
                        "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, " + ("RCCL" if backend == "nccl" else backend + " (rehearsal)") + ", overlapped with backward") if world > 1 else "none (1 rank)"},
-            "roofline": {"bound": "mfma", "kernel": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
-                                             "weight-gradient launch of the timed region)" % args.dtype,
-                         "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": pmc_traffic(args.workload, args.dtype, B), "launches": n_g, "avg_launch_ms": round(g_ms / max(n_g, 1), 4),
-                         "avg_launch_gflop": round(g_flops / max(n_g, 1) / 1e9, 2),
-                         "gemm_time_share_of_step": round(g_ms * 1e-3 / dt, 3),
-                         "whole_step_tflops_per_gpu": round(step_tflops, 1), "whole_step_frac": round(step_tflops / peak, 4)},
+            "roofline": {"bound": "mfma", "kernel": kernel_names[dom],
+                         "achieved": round(d["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
+                         "traffic": traffic, "traffic_note": traffic_src, "launches": d["launches"],
+                         "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                         "avg_launch_gflop": round(d["flops"] / max(d["launches"], 1) / 1e9, 2),
+                         "time_share_of_step": round(d["share"], 3),
+                         "other_family": {"kernel": other, "achieved": round(fam[other]["tflops"], 1), "launches": fam[other]["launches"],
+                                          "time_share_of_step": round(fam[other]["share"], 3)},
+                         "whole_step_tflops_per_gpu": round(step_tflops, 1), "whole_step_frac": round(step_tflops / peak, 4),
+                         "src_hash": source_hash()},
         }
         if mfma_stream:
             # context, not the contract's `peak`: what a register-only MFMA loop sustains on this device under its power management
             res["roofline"]["mfma_stream_measured"] = round(mfma_stream, 1)
-            res["roofline"]["frac_of_mfma_stream"] = round(achieved / mfma_stream, 4)
+            res["roofline"]["frac_of_mfma_stream"] = round(d["tflops"] / mfma_stream, 4)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, w, steps=args.cpu_steps)
             if cb is not None:

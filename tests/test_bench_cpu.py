@@ -1,0 +1,81 @@
+"""bench.py on a box without a GPU: the N-rank launcher protocol (UCFVIT_BENCH_DRY rehearsal), the work figures of the workloads against
+BASELINE.md §4, and the rule that a committed PMC traffic profile counts only for the kernel sources it was measured on."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra, timeout=180):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_2_starts_two_ranks_by_itself_and_relays_one_json_line():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns rank 0 and rank 1 (RANK / WORLD_SIZE / MASTER_* set),
+    they rendezvous (gloo here), time a barrier-bracketed region, take the MAX over ranks, rank 0 prints ONE JSON line"""
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1"], {"UCFVIT_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 4
+    assert d["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step, rank 0 one: the MAX over ranks is reported
+
+
+def test_world_size_must_match_gpus():
+    r = _run(["--gpus", "4"], {"UCFVIT_BENCH_DRY": "1", "WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+
+
+def test_parent_reports_a_failed_rank():
+    """a rank that dies (here: no GPU in this container and no dry switch) must fail the whole command, not hang or print a line"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0 and "ranks failed" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_work_figures_match_baseline_md():
+    """BASELINE.md §4 / SURVEY §8d: 369.4 GF per image (ViT-L), 105.4 (ViT-B), 122.5 (MAE ViT-L r = 0.75), 11.8 TF per volume (UNETR encoder)"""
+    import bench
+    f = lambda n: bench.train_flops_per_unit(bench.WORKLOADS[n])
+    assert abs(f("vit_l16_224") / 1e9 - 369.4) < 0.5
+    assert abs(f("vit_b16_224") / 1e9 - 105.4) < 0.3
+    assert abs(f("mae_vit_l16_224") / 1e9 - 122.5) < 0.3
+    assert abs(f("unetr_enc_512x512x128") / 1e12 - 11.8) < 0.1
+    assert bench.WORKLOADS["mae_vit_l16_224"]["batch"] * 49 % 256 == 0        # whole 256-row GEMM tiles for encoder and decoder rows
+
+
+def test_stale_pmc_profile_is_refused(tmp_path):
+    import bench
+    rec = {"workload": "vit_l16_224", "dtype": "bf16", "per_gpu_batch": 166, "src_hash": "0" * 16,
+           "families": {"gemm": {"hbm_bytes_per_launch_corrected": 123.0}}}
+    p = tmp_path / "r99_pmc_traffic_x.json"
+    p.write_text(json.dumps(rec))
+    val, note = bench.pmc_traffic("vit_l16_224", "bf16", 166, "gemm", profiles_dir=str(tmp_path))
+    assert val is None and note.startswith("stale")
+    rec["src_hash"] = bench.source_hash()
+    p.write_text(json.dumps(rec))
+    val, note = bench.pmc_traffic("vit_l16_224", "bf16", 166, "gemm", profiles_dir=str(tmp_path))
+    assert val == 123 and note == p.name
+    val, note = bench.pmc_traffic("vit_l16_224", "bf16", 128, "gemm", profiles_dir=str(tmp_path))
+    assert val is None
+
+
+def test_committed_pmc_profiles_of_this_round_carry_a_source_hash():
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]*pmc_traffic*.json")):
+        d = json.load(open(f))
+        assert len(d.get("src_hash", "")) == 16 and "families" in d, f

@@ -677,3 +677,117 @@ def test_empty_batch_forward_returns_empty_logits():
         with torch.no_grad():
             out = ma(torch.empty(0, 3, 12, 64, device=DEV), VARS, torch.empty(0, 12, 3, device=DEV))
         assert tuple(out.shape) == (0, 5)
+
+
+# ---------------------------------------------------------------------------------------------- checkpoint / resume
+def _resume_conf(tmp_path, load=None):
+    return {"trainer": {"checkpoint_path": str(tmp_path), "checkpoint_filename": "ck", "resume_from_checkpoint": load is not None,
+                        "checkpoint_filename_for_loading": load}}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_save_resume_continues_bit_exactly(tmp_path, dtype):
+    """train 3 steps, save_checkpoint (reference dictionary layout, train_class_simple.py:364-388), build a FRESH model + optimizer +
+    scheduler, maybe_resume (weights-only loader), and the next 2 steps are bit-equal to the uninterrupted 5-step run.  The saved
+    optimizer state is the torch.optim.AdamW layout: per-parameter {step, exp_avg, exp_avg_sq}, nothing else."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ucf-vit_amd", "training_scripts"))
+    import torch.distributed as dist
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
+    from _common import maybe_resume, save_checkpoint
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = torch.Generator().manual_seed(5)
+        xs = [torch.randn(4, 3, 32, 32, generator=g).to(DEV) for _ in range(5)]
+        ys = [torch.randint(0, 5, (4,), generator=g).to(DEV) for _ in range(5)]
+
+        def fresh():
+            m = build(VIT, VIT_KW, 31, dtype)
+            opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 1e-2)
+            sch = configure_scheduler(opt, 2, 10, 1e-8, 1e-8)
+            return m, opt, sch
+
+        def steps(m, opt, sch, lo, hi):
+            out = []
+            for i in range(lo, hi):
+                loss = cross_entropy_loss(m(xs[i], VARS), ys[i])
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                sch.step()
+                out.append(loss.item())
+            return out
+
+        m, opt, sch = fresh()
+        la = steps(m, opt, sch, 0, 5)
+        pa = m._ucf_store.flat_p.detach().clone()
+
+        m, opt, sch = fresh()
+        lb = steps(m, opt, sch, 0, 3)
+        sd = opt.state_dict()
+        assert set(sd["state"].keys()) == set(range(len(list(m.parameters()))))       # integer parameter indices only: no '_flat'
+        for ent in sd["state"].values():
+            assert set(ent.keys()) == {"step", "exp_avg", "exp_avg_sq"}
+        save_checkpoint(_resume_conf(tmp_path), 0, m, opt, sch, lb, 0)
+        ck = os.path.join(str(tmp_path), "ck_even.ckpt")
+        size_one = os.path.getsize(ck)
+        m2, opt2, sch2 = fresh()
+        start, ll = maybe_resume(_resume_conf(tmp_path, "ck_even"), m2, opt2, sch2)
+        assert start == 1 and ll == lb
+        lb2 = steps(m2, opt2, sch2, 3, 5)
+        assert lb + lb2 == la
+        assert torch.equal(m2._ucf_store.flat_p, pa)
+        # a second save after the resume does not grow (no dead copies of the moment buffers ride along)
+        save_checkpoint(_resume_conf(tmp_path), 0, m2, opt2, sch2, la, 0)
+        assert os.path.getsize(ck) < 1.05 * size_one
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
+def test_optimizer_loads_a_torch_adamw_state_dict():
+    """the reference's checkpoints hold torch.optim.AdamW state (utils/misc.py:67-82): it loads into the fused optimizer and the next
+    step equals torch's own"""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    from UCF_VIT.utils.misc import configure_optimizer
+    from UCF_VIT._hip.params import is_no_decay
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.randn(4, 3, 32, 32, generator=g).to(DEV), torch.randint(0, 5, (4,), generator=g).to(DEV)
+    m = build(VIT, VIT_KW, 32)
+    named = list(m.named_parameters())
+    groups = [dict(params=[p for n, p in named if not is_no_decay(n)], weight_decay=1e-2),
+              dict(params=[p for n, p in named if is_no_decay(n)], weight_decay=0.0)]
+    topt = torch.optim.AdamW(groups, lr=1e-3, betas=(0.9, 0.95))
+    for _ in range(2):
+        cross_entropy_loss(m(x, VARS), y).backward()
+        topt.step()
+        topt.zero_grad()
+    sd = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in topt.state_dict().items()}
+    sd["state"] = {i: {k: v.cpu() for k, v in e.items()} for i, e in topt.state_dict()["state"].items()}
+    w_before = {n: p.detach().clone() for n, p in named}
+    grads = None
+    # torch's third step
+    cross_entropy_loss(m(x, VARS), y).backward()
+    grads = {n: p.grad.detach().clone() for n, p in named}
+    topt.step()
+    want = {n: p.detach().clone() for n, p in named}
+    # rewind the weights, load the 2-step state into the fused optimizer, take the same third step
+    with torch.no_grad():
+        for n, p in named:
+            p.copy_(w_before[n])
+    hopt = configure_optimizer(m, 1e-3, 0.9, 0.95, 1e-2)
+    hopt.load_state_dict(sd)
+    for n, p in named:
+        p.grad = None
+    cross_entropy_loss(m(x, VARS), y).backward()
+    hopt.step()
+    for n, p in named:
+        assert rel_err(p.detach(), want[n]) < 1e-6, n

@@ -469,40 +469,6 @@ def test_adaptive_pos_embedding_fwd_bwd(dtype, B, S, D, kin, has_cls):
         assert rel_err(dc.cpu(), 2 * cr.grad.float()) < 1e-5
 
 
-def test_gemm_one_wave_per_simd_variant_matches(tmp_path):
-    """UCFVIT_GEMM_W4=1 routes KC x KC problems to the experimental 4-wave 256x256 kernel (128x128 per wave, accumulators in AGPRs,
-    software-pipelined fragment reads, DMA two K-tiles ahead): same results as torch on ragged M / N / K and every epilogue family.
-    The switch is read once per process, hence the child process."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    code = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from UCF_VIT._hip import ops
-from UCF_VIT._hip.lib import ACT_GELU
-torch.manual_seed(0)
-for M, N, K in [(3428, 4096, 128), (1000, 512, 256), (2500, 264, 192), (3400, 1024, 200), (33000, 1024, 1024)]:
-    x = torch.randn(M, K, device="cuda").bfloat16()
-    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-    b = torch.randn(N, device="cuda").bfloat16()
-    r = torch.randn(M, N, device="cuda").bfloat16()
-    ref = x.float() @ w.float().t() + b.float()
-    y = ops.linear_fwd(x, w, b)
-    assert ((y.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2, (M, N, K)
-    y = ops.linear_fwd(x, w, b, residual=r)
-    assert ((y.float() - (ref + r.float())).abs().max() / ref.abs().max()).item() < 1e-2, (M, N, K, "residual")
-    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    y = ops.linear_fwd(x, w, b, act=ACT_GELU, aux_out=h)
-    want = torch.nn.functional.gelu(ref.bfloat16().float())
-    assert ((y.float() - want).abs().max() / want.abs().max()).item() < 1e-2, (M, N, K, "gelu")
-print("ok")
-""" % os.path.join(ROOT, "ucf-vit_amd")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200, env=dict(os.environ, UCFVIT_GEMM_W4="1"))
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("V,R,D,dh", [(3, 24, 64, 32), (5, 1000, 1024, 64), (2, 333, 768, 64), (7, 130, 256, 128), (1, 50, 192, 64)])
 def test_variable_aggregation_attention_fwd_bwd(dtype, V, R, D, dh):

@@ -108,7 +108,7 @@ class HipDataParallel(nn.Module):
         self._ready = []
         self._callback_queued = False
         if self._hip:
-            _HF.add_wgrad_flush_listener(self._after_wgrad_flush)
+            _HF.add_wgrad_flush_listener(self._after_wgrad_flush, self.store)
         for p in params:
             if p.requires_grad:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -133,7 +133,7 @@ class HipDataParallel(nn.Module):
         b = self.param_bucket[p]
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
-            if self._hip and _HF.wgrads_pending():
+            if self._hip and _HF.wgrads_pending(self.store):
                 # weight gradients are queued for grouped launches that span several Blocks (functional.WgradQueue): this slice is
                 # complete for autograd but not yet on the stream; reduce it when the queue has flushed
                 self._ready.append(b)
@@ -186,7 +186,7 @@ class HipDataParallel(nn.Module):
 
     def _finish(self):
         if self._hip:
-            _HF.flush_wgrads()       # (also launches the buckets that were waiting for it)
+            _HF.flush_wgrads(self.store)       # (also launches the buckets that were waiting for it)
         # parameters that received no gradient this step (unused) leave their bucket incomplete: reduce it anyway so
         # every rank issues the same collectives in the same order
         for b in range(len(self.buckets)):

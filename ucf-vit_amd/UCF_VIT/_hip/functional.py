@@ -33,8 +33,14 @@ def _ret_grad(g, like):
 
 
 # ---------------------------------------------------------------------------------------------- param-grad helpers
+_QUEUES = weakref.WeakSet()      # every live queue (one per HipParamStore + the stand-alone one): flush_wgrads() walks them
+
+
 class WgradQueue:
-    """Weight gradients are off the critical path of backward: nothing reads them before the optimizer step (or a data-parallel
+    """Per-model backward context (one per HipParamStore: two models whose backward passes interleave — GAN-style training, tensor-
+    parallel threads — never see each other's pending gradients or column sums).
+
+    Weight gradients are off the critical path of backward: nothing reads them before the optimizer step (or a data-parallel
     all-reduce).  They are collected and issued as grouped launches (ucfvit_gemm_grouped: one persistent 256x256 ping-pong kernel
     over the union of the output tiles, no split-K partial sums).  One ViT-L Block has 192 tiles = 75 % of one round of 256 CUs,
     four Blocks have 768 = three whole rounds, so the queue keeps collecting ACROSS Blocks until the tile count fills whole
@@ -53,6 +59,11 @@ class WgradQueue:
         self.deferrable = True
         self.callback_armed = False
         self.listeners = []          # called after every flush (HipDataParallel launches the buckets that were waiting for it)
+        # one-slot hand-over of a residual-stream gradient's column sums between two autograd Functions of the SAME model (see
+        # publish_stream_colsum below): (dx tensor, fp32 [D] column sums)
+        self.stream_colsum = None
+        self.stream_colsum_armed = False
+        _QUEUES.add(self)
 
     def add(self, weight, dy2, x2):
         out, acc = grad_target(weight)
@@ -109,20 +120,42 @@ class WgradQueue:
 # UCFVIT_WGRAD_DEFER=0 keeps one launch per Block.
 _GROUP_WGRAD = os.environ.get("UCFVIT_WGRAD_GROUPED", "1") != "0"
 _DEFER_WGRAD = os.environ.get("UCFVIT_WGRAD_DEFER", "1") != "0"
-_WQ = WgradQueue()
+_STANDALONE_WQ = WgradQueue()     # modules used without a flat parameter store (single operators in tests)
 
 
-def flush_wgrads():
-    """issue every pending weight-gradient launch"""
-    _WQ.flush()
+def queue_of_store(store):
+    q = getattr(store, "_ucf_wq", None)
+    if q is None:
+        q = store._ucf_wq = WgradQueue()
+    return q
 
 
-def wgrads_pending():
-    return bool(_WQ.items)
+def _queue_for(p):
+    """the backward context of the model that owns parameter `p`"""
+    slot = getattr(p, "_ucf_slot", None)
+    if slot is not None and slot[0].owns(p, slot[1]):
+        return queue_of_store(slot[0])
+    return _STANDALONE_WQ
 
 
-def add_wgrad_flush_listener(bound_method):
-    _WQ.listeners.append(weakref.WeakMethod(bound_method))
+def flush_wgrads(store=None):
+    """issue every pending weight-gradient launch (of one model's store, or of every live model)"""
+    if store is not None:
+        queue_of_store(store).flush()
+        return
+    for q in list(_QUEUES):
+        q.flush()
+
+
+def wgrads_pending(store=None):
+    if store is not None:
+        return bool(queue_of_store(store).items)
+    return any(q.items for q in list(_QUEUES))
+
+
+def add_wgrad_flush_listener(bound_method, store=None):
+    q = queue_of_store(store) if store is not None else _STANDALONE_WQ
+    q.listeners.append(weakref.WeakMethod(bound_method))
 
 
 def _wgrad(weight, dy2, x2, queue=None):
@@ -155,31 +188,24 @@ def _ln_bwd(dy2, x2, gamma_c, mean, rstd, weight, bias, dres=None, dx_colsum=Non
 
 # The gradient of the residual stream leaves a LayerNorm backward (dx + dres) and is the output gradient of the Linear that wrote
 # into the stream before that norm: proj (inside the same Block) or fc2 (the Block before / the model's final norm).  Its column
-# sums = that Linear's bias gradient are taken by the LayerNorm-backward kernel; across autograd Functions they travel in this
-# one-slot cache, keyed by the tensor autograd hands on (held strongly until consumed or until backward ends, so its address
-# cannot be reused by another tensor in between).
-_STREAM_GRAD_COLSUM = [None]      # (dx tensor, fp32 [D] column sums)
+# sums = that Linear's bias gradient are taken by the LayerNorm-backward kernel; across autograd Functions they travel in a
+# one-slot cache of the model's backward context (WgradQueue.stream_colsum), keyed by the tensor autograd hands on (held strongly
+# until consumed or until backward ends, so its address cannot be reused by another tensor in between).
+def _publish_stream_colsum(q, dx, cs):
+    q.stream_colsum = (dx, cs)
+    if not q.stream_colsum_armed:
+        q.stream_colsum_armed = True
+
+        def clear():
+            q.stream_colsum = None
+            q.stream_colsum_armed = False
+        torch.autograd.Variable._execution_engine.queue_callback(clear)
 
 
-def _publish_stream_colsum(dx, cs):
-    _STREAM_GRAD_COLSUM[0] = (dx, cs)
-    if not _STREAM_GRAD_COLSUM_ARMED[0]:
-        _STREAM_GRAD_COLSUM_ARMED[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_clear_stream_colsum)
-
-
-_STREAM_GRAD_COLSUM_ARMED = [False]
-
-
-def _clear_stream_colsum():
-    _STREAM_GRAD_COLSUM[0] = None
-    _STREAM_GRAD_COLSUM_ARMED[0] = False
-
-
-def _take_stream_colsum(dy2):
+def _take_stream_colsum(q, dy2):
     """column sums of dy2 if the LayerNorm backward that produced exactly this tensor published them, else None"""
-    ent = _STREAM_GRAD_COLSUM[0]
-    _STREAM_GRAD_COLSUM[0] = None
+    ent = q.stream_colsum
+    q.stream_colsum = None
     if ent is None or not _BIAS_FROM_EPILOGUE:
         return None
     dx, cs = ent
@@ -367,7 +393,7 @@ class LayerNormFn(torch.autograd.Function):
         cs = torch.empty(x2.shape[1], dtype=torch.float32, device=dy2.device) if (_BIAS_FROM_EPILOGUE and ctx.in_dtype == ctx.cdtype) else None
         dx, dg, db = _ln_bwd(dy2, x2, compute_param(weight, ctx.cdtype), mean, rstd, weight, bias, dx_colsum=cs)
         if cs is not None:
-            _publish_stream_colsum(dx, cs)      # e.g. the model's final norm: its dx is the last Block's output gradient
+            _publish_stream_colsum(_queue_for(weight), dx, cs)      # e.g. the model's final norm: its dx is the last Block's output gradient
         return _ret_grad(dx.view(ctx.in_shape), ctx.in_dtype), dg, db, None, None
 
 
@@ -446,8 +472,8 @@ class BlockFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         c = lambda p: compute_param(p, cdtype)
         dy2 = _as(dy, cdtype).reshape(x2.shape)
-        wq = _WQ
-        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq, dy2_colsum=_take_stream_colsum(dy2))
+        wq = _queue_for(qkvw)
+        dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq, dy2_colsum=_take_stream_colsum(wq, dy2))
         # LayerNorm backward also sums its output (the residual-stream gradient) over the tokens: proj's bias gradient here ...
         projb_done = None
         pb_out, pb_acc = None, False
@@ -464,7 +490,7 @@ class BlockFn(torch.autograd.Function):
         cs0 = torch.empty(x2.shape[1], dtype=torch.float32, device=dy2.device) if _BIAS_FROM_EPILOGUE else None
         dx, g_n1w, g_n1b = _ln_bwd(dln1, x2, c(n1w), mean1, rstd1, n1w, n1b, dres=dx1, dx_colsum=cs0)
         if cs0 is not None and in_dtype == cdtype:
-            _publish_stream_colsum(dx, cs0)
+            _publish_stream_colsum(wq, dx, cs0)
         wq.end_block()                                   # the Block's 4 weight gradients: grouped launch now, or with the next Blocks'
         return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None)
 

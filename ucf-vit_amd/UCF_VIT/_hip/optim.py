@@ -15,6 +15,16 @@ class HipAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.grad_scale = grad_scale  # multiplies gradients inside the kernel (e.g. 1/world_size, or 1/loss_scale)
+        # flat moment buffers of the one-launch path, keyed (id(store), lo, hi).  They live on the optimizer object, NOT in self.state:
+        # state_dict() then serialises only the per-parameter {step, exp_avg, exp_avg_sq} entries (views into these buffers) — the
+        # torch.optim.AdamW layout the reference's checkpoints hold (train_class_simple.py:364-388) — and nothing keyed by an id()
+        self._flat = {}
+
+    def load_state_dict(self, state_dict):
+        """accepts a torch.optim.AdamW / HipAdamW state_dict; the flat buffers are rebuilt from the per-parameter entries on the next
+        step (the loaded tensors are copied in, so a checkpoint mapped to the CPU ends up in device memory before any kernel sees it)"""
+        super().load_state_dict(state_dict)
+        self._flat = {}
 
     @staticmethod
     def _adopt_foreign_grads(group):
@@ -62,7 +72,7 @@ class HipAdamW(torch.optim.Optimizer):
             run = self._flat_run(group)
             if run is not None:
                 st, lo, hi = run
-                fs = self.state.setdefault("_flat", {})
+                fs = self._flat
                 key = (id(st), lo, hi)
                 ent = fs.get(key)
                 if ent is None:
@@ -73,8 +83,8 @@ class HipAdamW(torch.optim.Optimizer):
                         s = self.state.get(p)
                         if s and "exp_avg" in s:
                             o = p._ucf_slot[1] - lo
-                            ent["m"][o:o + p.numel()].copy_(s["exp_avg"].reshape(-1))
-                            ent["v"][o:o + p.numel()].copy_(s["exp_avg_sq"].reshape(-1))
+                            ent["m"][o:o + p.numel()].copy_(s["exp_avg"].reshape(-1).to(ent["m"].device, torch.float32))
+                            ent["v"][o:o + p.numel()].copy_(s["exp_avg_sq"].reshape(-1).to(ent["v"].device, torch.float32))
                             ent["step"] = int(s["step"])
                     for p in group["params"]:
                         o = p._ucf_slot[1] - lo

@@ -128,7 +128,6 @@ struct Epi2 {
     int act, accumulate;
     float alpha;
     float* slab;       // split-K: fp32 partial matrices [splits][M][N] (ld = N); NULL when gridDim.y == 1
-    unsigned long long* dbg;  // diagnostic stamps (UCFVIT_GEMM_DBG builds of the bench only); NULL in production
     float* cs_partial; // column sums of the output per 128-row block: [2 * tiles_m][N] (CS instantiations only), or NULL
 };
 
@@ -136,13 +135,9 @@ __device__ int g_band_override = 0;      // experiments: UCFVIT_GEMM_BAND=n forc
 
 // logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
 __device__ __forceinline__ void tile_origin(int t, int tiles_m, int tiles_n, int BM, int BN, int& m0, int& n0) {
-#ifdef UCFVIT_DBG_BAND8
-    const int BAND = 8;
-#else
     // 12 N-tiles (the qkv projection: N = 3072) as three bands of 4 rather than 8 + 4: every XCD block is 8 x 4 tiles
     const int ov = g_band_override;
     const int BAND = ov ? ov : ((tiles_n > 8 && tiles_n % 8 != 0 && tiles_n % 4 == 0) ? 4 : 8);
-#endif
     const int band_tiles = BAND * tiles_m;
     const int band = t / band_tiles;
     const int band_w = min(BAND, tiles_n - band * BAND);
@@ -233,7 +228,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 
         for (int kt = 0; kt < nk; ++kt, ++it) {
             // K-tile `it` has landed (vmcnt(0) of every wave, then the barrier); everyone is done with the other buffer
@@ -270,12 +264,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
         //   phase B: each lane owns 8 consecutive columns of a row: activation / aux / residual / accumulate, 16-B loads+stores
         // The staging area is the pipeline buffer of the K-tile just consumed; the other buffer is receiving the next tile's
         // first K-tile, so only LDS reads (not the DMA) are waited for here: raw barrier, no vmcnt.
-        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
         float* stage = reinterpret_cast<float*>(smem + ((it - 1) & 1) * BUF) + wave * (16 * PADW);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -374,301 +366,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
                 }
             }
         }
-        if (ep.dbg && tid == 0 && round < 8) ep.dbg[(blockIdx.x * 8 + round) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
         if (!has_next) break;
         cur = nxt;
         sched_round = next_round;
     }
-}
-
-// =====================================================================================================================
-// ONE WAVE PER SIMD variant of the persistent 256x256x64 kernel: 4 waves (2 x 2), 128x128 output per wave, the 256 accumulator
-// registers in AGPRs.  A wave reads 16 fragments per 64 MFMAs (the 8-wave kernels read 12 per 32): a third fewer LDS bytes per MFMA.
-// With one wave per SIMD nothing else hides a fragment read, so the wave pipelines itself: the fragments of half-step (kt, c ^ 1)
-// are read into a second register set while the 64 MFMAs of (kt, c) issue.  LDS-DMA runs two K-tiles ahead; the one barrier per
-// K-tile sits at its midpoint, where every wave has finished READING K-tile kt (its second half is in registers) and its own DMA
-// pieces of K-tile kt+1 have landed: after it, K-tile kt+2 is issued into kt's buffer and kt+1 may be read.
-//   K-tile kt:  [ MFMA(kt,c0) || reads(kt,c1) ] -> lgkmcnt(0), vmcnt(0), barrier, DMA(kt+2) -> [ MFMA(kt,c1) || reads(kt+1,c0) ]
-// The epilogue stages through its own 17-KiB LDS region (both pipeline buffers are busy at a tile boundary).  KC x KC operands only.
-// =====================================================================================================================
-template <typename OutT>
-__device__ __forceinline__ void epi4_row8(float* v, int m, int n, OutT* __restrict__ C, const Epi2& ep) {
-    if (ep.act == UCFVIT_ACT_GELU) {
-        if (ep.aux_out) {
-            Vec16<bf16> o;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-            *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = o.get(r);
-        }
-        gelu_fast8(v);
-    } else if (ep.act == UCFVIT_ACT_GELU_GRAD) {
-        const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
-        float hf[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) hf[r] = h.get(r);
-        gelu_grad_fast8(v, hf);
-    } else if (ep.act == UCFVIT_ACT_GELU_SAVE_DERIV) {
-        float df[8];
-        gelu_and_grad_fast8(v, df);
-        Vec16<bf16> o;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o.set(r, df[r]);
-        *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
-    } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
-        const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= h.get(r);
-    }
-    if (ep.residual) {
-        const Vec16<bf16> rv = *reinterpret_cast<const Vec16<bf16>*>(ep.residual + (int64_t)m * ep.ldr + n);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rv.get(r);
-    }
-    OutT* cp = C + (int64_t)m * ep.ldc + n;
-    if constexpr (sizeof(OutT) == 2) {
-        if (ep.accumulate) {
-            const Vec16<bf16> old = *reinterpret_cast<const Vec16<bf16>*>(cp);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += old.get(r);
-        }
-        Vec16<bf16> o;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-        *reinterpret_cast<Vec16<bf16>*>(cp) = o;
-    } else {
-        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        if (ep.accumulate) {
-            o0 += *reinterpret_cast<const f32x4*>(cp);
-            o1 += *reinterpret_cast<const f32x4*>(cp + 4);
-        }
-        *reinterpret_cast<f32x4*>(cp) = o0;
-        *reinterpret_cast<f32x4*>(cp + 4) = o1;
-    }
-}
-
-constexpr int G4_STAGE_OFF = 2 * (256 + 256) * 128;            // after the two pipeline buffers
-constexpr int G4_PADW = 32 + 4;                                // staged row: 32 fp32 columns + pad
-constexpr int G4_SMEM = G4_STAGE_OFF + 4 * 32 * G4_PADW * 4;   // 149504 bytes
-
-template <typename OutT>
-__global__ __launch_bounds__(256) void gemm4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, OutT* __restrict__ C, int M, int N,
-                                                    int K, int64_t lda, int64_t ldb, Epi2 ep, int tiles_m, int tiles_n) {
-    constexpr int KC = UCFVIT_LAYOUT_KC;
-    constexpr int BM = 256, BN = 256;
-    constexpr int A_BYTES = BM * 128, BUF = (BM + BN) * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
-    const int tiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
-    const int nk = (K + BK2 - 1) / BK2;
-    const int klast = K - (nk - 1) * BK2;
-
-    // position in the flat sequence of (output tile, K-tile) pairs of this workgroup
-    auto tile_at = [&](int round, int& m0, int& n0) -> bool {
-        const int base = round * G;
-        if (base >= tiles) return false;
-        const int cnt = min(G, tiles - base);
-        if (bid >= cnt) return false;
-        tile_origin(base + xcd_remap(bid, cnt), tiles_m, tiles_n, BM, BN, m0, n0);
-        return true;
-    };
-    int c_round = 0, c_m0 = 0, c_n0 = 0;                  // compute cursor (output tile)
-    if (!tile_at(0, c_m0, c_n0)) return;
-    int p_round = 0, p_kt = 0, p_m0 = c_m0, p_n0 = c_n0;  // prefetch cursor
-    bool p_valid = true;
-    int pf_it = 0;                                        // running index of the K-tile the prefetch cursor points at
-    // per-lane byte offsets of this wave's 8 + 8 DMA pieces inside the prefetch cursor's output tile (rows clamped at the matrix edge);
-    // the K position is a wave-uniform offset added at issue time, so one issue = one 64-bit add + the DMA instruction
-    unsigned poffA[8], poffB[8];
-    auto piece_offsets = [&](unsigned (&off)[8], int64_t ld, int r0, int R) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (wave * 8 + i) * 8 + (lane >> 3);
-            const int gslot = (lane & 7) ^ ((row >> 1) & 7);      // this kernel's swizzle (see the fragment reads)
-            int gr = r0 + row;
-            gr = gr < R ? gr : R - 1;
-            off[i] = (unsigned)(((int64_t)gr * ld + gslot * 8) * 2);
-        }
-    };
-    piece_offsets(poffA, lda, p_m0, M);
-    piece_offsets(poffB, ldb, p_n0, N);
-    auto prefetch = [&]() {
-        if (!p_valid) return;
-        char* dst = smem + (pf_it & 1) * BUF;
-        {                                                 // (K is a multiple of 64 here: the dispatcher sends ragged K elsewhere)
-            const char* ak = reinterpret_cast<const char*>(A) + (int64_t)p_kt * (BK2 * 2);
-            const char* bk = reinterpret_cast<const char*>(B) + (int64_t)p_kt * (BK2 * 2);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(ak + poffA[i]), (lptr_t)(dst + (wave * 8 + i) * 1024), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(bk + poffB[i]), (lptr_t)(dst + A_BYTES + (wave * 8 + i) * 1024), 16, 0, 0);
-        }
-        ++pf_it;
-        if (++p_kt == nk) {
-            p_kt = 0;
-            ++p_round;
-            p_valid = tile_at(p_round, p_m0, p_n0);
-            if (p_valid) {
-                piece_offsets(poffA, lda, p_m0, M);
-                piece_offsets(poffB, ldb, p_n0, N);
-            }
-        }
-    };
-    prefetch();
-    prefetch();
-
-    // ---- 32x32x16 MFMAs (a single wave issues this shape at the full matrix-pipe rate; with 16x16x32 one wave per SIMD tops out at
-    // about two thirds of it: tools/mfma_peak.hip).  Wave tile = 4 x 4 tiles of 32 x 32, a K-tile = 4 steps of 16.
-    // Fragment of rows r0..r0+31, step kk: lane l reads the 8 contraction elements of slot 2 kk + (l >> 5) in row r0 + (l & 31).
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    constexpr int TI = 4, TJ = 4;
-    u32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
-    const int frow = lane & 31, fhalf = lane >> 5;
-    // Fragment reads are inline asm too (ds_read_b128 with one address register per operand and step: the 32-row tile index is an
-    // immediate offset), so hipcc neither drains lgkmcnt in front of an MFMA nor re-orders anything: the read burst of step s+1 is
-    // issued FIRST, then `s_waitcnt lgkmcnt(8)` lets exactly those eight stay in flight while the 16 MFMAs of step s issue.
-    //   byte offset of (row r0 + frow, slot 2 kk + fhalf) = (r0 + frow) * 128 + (((2 kk + fhalf) ^ ((frow >> 1) & 7)) << 4),  r0 = 32 i (+ wm)
-    // Swizzle: a ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) and a row starts at bank
-    // 0 or 32 by its parity, so the 8 even and the 8 odd rows of a group must use 8 different 16-byte slots: (row >> 1) & 7 does that
-    // for the 32-row fragments of this MFMA shape (the (row & 7) swizzle of the 16-row kernels is 2-way conflicted here).
-    unsigned xk[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xk[kk] = (unsigned)((((2 * kk + fhalf) ^ ((frow >> 1) & 7)) << 4) + frow * 128);
-    const unsigned ldsA = lds_addr(smem) + (unsigned)(wm * 128), ldsB = lds_addr(smem) + (unsigned)(A_BYTES + wn * 128);
-#ifdef UCFVIT_DBG_G4_NOREAD   /* timing experiment: no fragment reads at all (wrong results) */
-#define G4_RD(dst_, addr_, off_) asm volatile("" : "+v"(dst_) : "v"(addr_))
-#else
-#define G4_RD(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
-#endif
-#define G4_READ(fa_, fb_, bufoff_, kk_)                                                        \
-    do {                                                                                       \
-        const unsigned aa = ldsA + (bufoff_) + xk[kk_], ab = ldsB + (bufoff_) + xk[kk_];       \
-        G4_RD(fb_[0], ab, 0); G4_RD(fb_[1], ab, 4096); G4_RD(fb_[2], ab, 8192); G4_RD(fb_[3], ab, 12288); \
-        G4_RD(fa_[0], aa, 0); G4_RD(fa_[1], aa, 4096); G4_RD(fa_[2], aa, 8192); G4_RD(fa_[3], aa, 12288); \
-    } while (0)
-// The MFMAs are inline asm with the accumulator tied in place in an AGPR ("+a"): with all 256 AGPRs holding accumulators hipcc's
-// allocator otherwise un-ties destination and addend of most MFMAs and copies the tile in front of each (measured: 2x slower loop).
-// Roles swapped as in the other kernels: D[n][m], lane l holds m = l & 31 and n = 8 b + 4 (l >> 5) + r in register 4 b + r.
-#define G4_MFMA_ROWS(fa_, fb_, I0_, I1_)                                                       \
-    do {                                                                                       \
-        _Pragma("unroll") for (int i = I0_; i < I1_; ++i)                                      \
-            _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                     \
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb_[j]), "v"(fa_[i])); \
-    } while (0)
-// one step: read burst of the next step into the other set, counted wait for THIS step's set, 16 MFMAs
-#define G4_STEP(fa_, fb_, nfa_, nfb_, nbufoff_, nkk_, do_read_)                                 \
-    do {                                                                                       \
-        if (do_read_) {                                                                        \
-            G4_READ(nfa_, nfb_, nbufoff_, nkk_);                                               \
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                 \
-        } else {                                                                               \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
-        }                                                                                      \
-        G4_MFMA_ROWS(fa_, fb_, 0, TI);                                                         \
-    } while (0)
-
-    // the first K-tile: wait for it (the second one, 16 wave-instructions, may stay in flight), make it visible, read its first step
-    if (nk > 1 || p_valid || p_round > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int it = 0;
-    G4_READ(fa0, fb0, 0u, 0);
-
-    for (;;) {
-        const int m0 = c_m0, n0 = c_n0;
-        f32x16 acc[TI][TJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        int n_m0 = 0, n_n0 = 0;
-        const bool has_next = tile_at(c_round + 1, n_m0, n_n0);
-#pragma clang loop unroll(disable)
-        for (int kt = 0; kt < nk; ++kt, ++it) {
-            const unsigned boff = (unsigned)((it & 1) * BUF), nboff = (unsigned)(((it + 1) & 1) * BUF);
-            G4_STEP(fa0, fb0, fa1, fb1, boff, 1, true);
-            G4_STEP(fa1, fb1, fa0, fb0, boff, 2, true);
-            // step 2 -> 3: the last reads of this K-tile go out, then everything this wave has read or DMA-issued is waited for
-            G4_READ(fa1, fb1, boff, 3);
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            G4_MFMA_ROWS(fa0, fb0, 0, TI);
-#ifdef UCFVIT_DBG_G4_NOVM
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my reads of this K-tile are done; my DMA pieces of K-tile it+1 have landed
-#endif
-#ifndef UCFVIT_DBG_G4_NOBAR
-            __builtin_amdgcn_s_barrier();
-#endif
-#ifndef UCFVIT_DBG_G4_NODMA
-            prefetch();                                     // K-tile it+2 -> this K-tile's buffer
-#endif
-            const bool more = (kt + 1 < nk) || has_next;
-            G4_STEP(fa1, fb1, fa0, fb0, nboff, 0, more);    // first step of the next K-tile (possibly of the next output tile)
-        }
-
-        // the asm MFMAs are opaque to the hazard recogniser: let the last results retire before the accumulators are read
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        // ---- epilogue: one 32 x 32 accumulator tile at a time through a wave-private staging tile.  The tile-row loop is a real loop
-        // (one copy of the row code); the accumulators keep compile-time indices through the switch.
-        float* stage = reinterpret_cast<float*>(smem + G4_STAGE_OFF) + wave * (32 * G4_PADW);
-        const int prow = lane >> 2, pcol = (lane & 3) * 8;
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < TI; ++i) {
-            f32x16 row[TJ];
-#define G4_TAKE(I_) _Pragma("unroll") for (int j = 0; j < TJ; ++j) row[j] = acc[I_][j]
-            switch (i) {
-                case 0: G4_TAKE(0); break;
-                case 1: G4_TAKE(1); break;
-                case 2: G4_TAKE(2); break;
-                default: G4_TAKE(3); break;
-            }
-#undef G4_TAKE
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int nl = 8 * b + 4 * fhalf;
-                    f32x4 v = {row[j][4 * b], row[j][4 * b + 1], row[j][4 * b + 2], row[j][4 * b + 3]};
-                    const int n = n0 + wn + 32 * j + nl;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= ep.alpha;
-                    if (ep.bias && n < N) {
-                        const Vec4<bf16> bb = *reinterpret_cast<const Vec4<bf16>*>(ep.bias + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += bb.get(r);
-                    }
-                    *reinterpret_cast<f32x4*>(stage + frow * G4_PADW + nl) = v;
-                }
-#pragma unroll
-                for (int rr = 0; rr < 32; rr += 16) {
-                    const int rw = rr + prow;
-                    const int m = m0 + wm + 32 * i + rw;
-                    const int n = n0 + wn + 32 * j + pcol;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + rw * G4_PADW + pcol);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + rw * G4_PADW + pcol + 4);
-                    if (m >= M || n >= N) continue;
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    epi4_row8<OutT>(v, m, n, C, ep);
-                }
-            }
-        }
-        if (!has_next) break;
-        ++c_round;
-        c_m0 = n_m0;
-        c_n0 = n_n0;
-    }
-#undef G4_RD
-#undef G4_STEP
-#undef G4_READ
-#undef G4_MFMA_ROWS
 }
 
 // =====================================================================================================================
@@ -902,15 +603,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
             if constexpr (LB == UCFVIT_LAYOUT_KS) { _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = ks_frag_value(kb[j]); } \
         }                                                                                      \
     } while (0)
-#ifdef UCFVIT_DBG_NOMFMA   /* timing experiment only (wrong results): fragments are consumed, 2 of 32 MFMAs issued */
-#define PP_COMPUTE()                                                                           \
-    do {                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(fa[i]));          \
-        _Pragma("unroll") for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(fb[j]));          \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0], acc[0][0], 0, 0, 0); \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1], acc[1][1], 0, 0, 0); \
-    } while (0)
-#else
 #define PP_COMPUTE()                                                                           \
     do {                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                         \
@@ -919,7 +611,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                         \
     } while (0)
-#endif
 #define PP_ISSUE_ONE(LAY_, BR_, base_, ld_, off_, nbase_, nld_, r0n_, Rn_, ldsoff_, kt_)         \
     do {                                                                                       \
         char* nb = smem + ((it + 1) & 1) * BUF + (ldsoff_);                                    \
@@ -950,19 +641,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
             if constexpr (LB == UCFVIT_LAYOUT_KS) asm volatile("" : "+v"(ksB));   // recomputed, not hoisted into 12 live VGPRs
             PP_ISSUE_B(kt);                 // MEM(c0): DMA of this group's half of the next B tile (read by BOTH groups) ...
             PP_ISSUE_A(kt);                 // ... and of its OWN rows of the next A tile (that region was last read in MEM(c1) of the tile before)
-#ifdef UCFVIT_DBG_NOREAD   /* timing experiment only (wrong results): fragment reads on the first K-tile only */
-            if (kt == 0) PP_READ(bufA, bufB, 0);
-#else
             PP_READ(bufA, bufB, 0);
-#endif
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c0)
             PP_BARRIER();
-#ifdef UCFVIT_DBG_NOREAD
-            if (kt == 0) PP_READ(bufA, bufB, 1);
-#else
             PP_READ(bufA, bufB, 1);         // MEM(c1): fragment reads only
-#endif
             if (grp == 1) PP_WAIT_B();      // G1's B half (issued 2 intervals ago) must be visible before G0's next MEM(c0); its A pieces stay in flight
             PP_BARRIER();
             PP_COMPUTE();                   // COMPUTE(c1)
@@ -1471,45 +1154,10 @@ static bool pp_enabled() {
     return flag == 1;
 }
 
-template <typename OutT>
-int launch4(const ucfvit_gemm_desc* d, Epi2 ep, hipStream_t s) {
-    const int tiles_m = (int)((d->M + 255) / 256), tiles_n = (int)((d->N + 255) / 256);
-    auto kern = gemm4_kernel<OutT>;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G4_SMEM);
-        if (e != hipSuccess) {
-            ucfvit_set_error("ucfvit_gemm: cannot raise dynamic LDS to %d bytes: %s", G4_SMEM, hipGetErrorString(e));
-            return UCFVIT_ERR_HIP;
-        }
-        done = true;
-    }
-    const int tiles = tiles_m * tiles_n;
-    const int gx = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), G4_SMEM, s, (const bf16*)d->A, (const bf16*)d->B, (OutT*)d->C, (int)d->M, (int)d->N,
-                       (int)d->K, d->lda, d->ldb, ep, tiles_m, tiles_n);
-    UCF_LAUNCH_CHECK("ucfvit_gemm(v4 one wave per SIMD)");
-    return UCFVIT_OK;
-}
-
-static bool w4_enabled() {
-    static int flag = -1;
-    if (flag < 0) {
-        const char* e = getenv("UCFVIT_GEMM_W4");
-        flag = (e && e[0] == '1') ? 1 : 0;
-    }
-    return flag == 1;
-}
-
 template <int LA, int LB, typename OutT>
 int dispatch_tile(const ucfvit_gemm_desc* d, const Plan2& p, const Epi2& ep, hipStream_t s) {
     const int64_t a_bytes = ((d->a_layout == UCFVIT_LAYOUT_KC ? d->M : d->K) * d->lda) * 2;
     const int64_t b_bytes = ((d->b_layout == UCFVIT_LAYOUT_KC ? d->N : d->K) * d->ldb) * 2;
-    if constexpr (LA == UCFVIT_LAYOUT_KC && LB == UCFVIT_LAYOUT_KC) {
-        if (p.big && w4_enabled() && p.splits == 1 && !ep.slab && !ep.cs_partial && d->K >= 2 * BK2 && d->K % BK2 == 0 && a_bytes < (1ll << 32) &&
-            b_bytes < (1ll << 32))
-            return launch4<OutT>(d, ep, s);
-    }
     if (p.big && pp_enabled() && a_bytes < (1ll << 32) && b_bytes < (1ll << 32)) return launch3<LA, LB, OutT>(d, p, ep, s);
     if (p.big) return launch2<LA, LB, 256, 256, 2, 4, OutT>(d, p, ep, s);
     return launch2<LA, LB, 128, 128, 2, 2, OutT>(d, p, ep, s);
@@ -1585,10 +1233,6 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
             return UCFVIT_ERR_UNSUPPORTED;
         }
         ep.cs_partial = d->c_colsum_partial;
-    }
-    {
-        const char* e = getenv("UCFVIT_GEMM_DBG");
-        ep.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
     }
     if (p.splits > 1) {
         const int64_t need = (int64_t)p.splits * d->M * d->N * (int64_t)sizeof(float);

@@ -154,7 +154,7 @@ def maybe_resume(conf, model, optimizer, scheduler):
     t = conf["trainer"]
     if not t.get("resume_from_checkpoint", False):
         return 0, []
-    ck = torch.load(os.path.join(t["checkpoint_path"], t["checkpoint_filename_for_loading"] + ".ckpt"), map_location="cpu", weights_only=False)
+    ck = torch.load(os.path.join(t["checkpoint_path"], t["checkpoint_filename_for_loading"] + ".ckpt"), map_location="cpu", weights_only=True)
     model.load_state_dict(ck["model_state_dict"])
     optimizer.load_state_dict(ck["optimizer_state_dict"])
     scheduler.load_state_dict(ck["scheduler_state_dict"])
