@@ -286,7 +286,7 @@ def test_unetr_encoder_full_size_512x512x128():
     assert tuple(feats.shape) == (1, 8192, 768) and len(taps) == 3
     for t in taps:
         assert tuple(t.shape) == (1, 8192, 768) and torch.isfinite(t.float()).all()
-    f = feats.float()
+    f = feats.detach().float()
     w, b = m.norm.weight.float(), m.norm.bias.float()
     z = (f - b) / w                                      # undo the affine part: rows of zero mean and unit variance
     assert float(z.mean(dim=-1).abs().max()) < 2e-2 and float((z.var(dim=-1, unbiased=False) - 1).abs().max()) < 5e-2

@@ -113,7 +113,7 @@ def _hip_dp_worker(rank, world, port, q, reduce_dtype=None):
         w = m._ucf_store.flat_p.detach().cpu()
         w0 = w.clone()
         dist.broadcast(w0, 0)
-        q.put((rank, bad, bool(torch.equal(w, w0)), "_flat" in opt.state))
+        q.put((rank, bad, bool(torch.equal(w, w0)), bool(opt._flat)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
