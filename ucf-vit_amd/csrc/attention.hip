@@ -41,6 +41,12 @@ template <> struct Mma16<bf16> {
     static __device__ __forceinline__ void mma(f32x4& acc, const frag_t& a, const frag_t& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ frag_t ones() {
+        frag_t r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (bf16)1.0f;
+        return r;
+    }
 };
 template <> struct Mma16<float> {
     typedef f32x4 frag_t;
@@ -48,6 +54,7 @@ template <> struct Mma16<float> {
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ frag_t ones() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
 };
 
 template <typename T, int DH> struct AT {
@@ -152,6 +159,13 @@ __device__ __forceinline__ typename AT<T, DH>::frag_t frag_global(const T* __res
     return __builtin_bit_cast(frag_t, v);
 }
 
+// max(a, b, c) as ONE instruction: hipcc puts a canonicalising v_max_f32 x, x, x in front of every fmaxf of an MFMA result
+// (32 extra VALU instructions per key tile of the forward kernel, which is bound by its VALU work)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float group_max(float v) {  // over the 4 lane groups that share lane&15
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -162,16 +176,62 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ===================================================================================================
+// Streaming kernels.  Template parameters shared by all three:
+//   QB   = 16-row blocks of the lane-resident index per wave (queries for forward / dQ, keys for dK/dV).  Every K / V (Q / dO) fragment
+//          read from LDS feeds QB MFMAs, so QB = 2 halves the LDS bytes per MFMA of the QB = 1 form (which was bound by them).
+//   NBUF = LDS buffers per tile stream.  2: the next tile is written into the other buffer while this one is being read: ONE barrier per
+//          tile; 1: store / barrier / compute / barrier (fp32 at head dim 128: 64 KB per tile pair).
+// A workgroup is 4 waves = 64 QB rows of the resident index; the streamed index advances in tiles of KT = 64 rows.
+// ===================================================================================================
+template <typename T, int DH, int NBUF> struct Stream {
+    static constexpr int PAIR = 2 * AT<T, DH>::TILE_BYTES;      // the two tiles of one step (K+V or Q+dO)
+    // top of step t: registers hold tile t+1 (NBUF 2) or tile t (NBUF 1)
+    template <typename LoadNext>
+    static __device__ __forceinline__ char* begin(char* smem, int t, int ntiles, TileStage<T, DH>& s0, TileStage<T, DH>& s1, int tid, LoadNext load) {
+        if constexpr (NBUF == 2) {
+            char* cur = smem + (t & 1) * PAIR;
+            if (t + 1 < ntiles) {
+                char* nxt = smem + ((t + 1) & 1) * PAIR;            // last read in step t-1: every wave has passed that step's barrier
+                tile_store<T, DH>(s0, nxt, tid);
+                tile_store<T, DH>(s1, nxt + AT<T, DH>::TILE_BYTES, tid);
+                if (t + 2 < ntiles) load(t + 2);                    // in flight during this step's MFMAs
+            }
+            return cur;
+        } else {
+            __syncthreads();
+            tile_store<T, DH>(s0, smem, tid);
+            tile_store<T, DH>(s1, smem + AT<T, DH>::TILE_BYTES, tid);
+            __syncthreads();
+            if (t + 1 < ntiles) load(t + 1);
+            return smem;
+        }
+    }
+    static __device__ __forceinline__ void end() {
+        if constexpr (NBUF == 2) __syncthreads();
+    }
+    // before the loop: tile 0 into LDS (NBUF 2) and the first register tile loaded
+    template <typename LoadNext>
+    static __device__ __forceinline__ void prime(char* smem, int ntiles, TileStage<T, DH>& s0, TileStage<T, DH>& s1, int tid, LoadNext load) {
+        load(0);
+        if constexpr (NBUF == 2) {
+            tile_store<T, DH>(s0, smem, tid);
+            tile_store<T, DH>(s1, smem + AT<T, DH>::TILE_BYTES, tid);
+            if (ntiles > 1) load(1);
+            __syncthreads();
+        }
+    }
+};
+
+// ===================================================================================================
 // forward
 // ===================================================================================================
-template <typename T, int DH>
+template <typename T, int DH, int QB, int NBUF>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
                                                                int N, int H, float scale_log2e) {
     typedef AT<T, DH> A;
     typedef typename A::frag_t frag_t;
+    typedef Stream<T, DH, NBUF> ST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsK = smem;
-    char* ldsV = smem + A::TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
@@ -180,85 +240,121 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     const T* qbase = qkv + b * N * rs + h * DH;
     const T* kbase = qbase + D;
     const T* vbase = qbase + 2 * D;
-    const int q = blockIdx.x * 64 + wave * 16 + li;
+    const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB) + li;     // query of block qb: q0 + 16 qb
 
-    frag_t qf[A::NCH];
+    frag_t qf[QB][A::NCH];
 #pragma unroll
-    for (int c = 0; c < A::NCH; ++c) qf[c] = frag_global<T, DH>(qbase, rs, q, N, c, lane);
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) qf[qb][c] = frag_global<T, DH>(qbase, rs, q0 + 16 * qb, N, c, lane);
 
-    f32x4 o[A::NDB];
+    f32x4 o[QB][A::NDB];
+    // the row sums of P ride on the matrix pipe: an all-ones A fragment times Pᵀ gives, in EVERY accumulator row, the sum over the tile's
+    // keys of the (rounded) probabilities that also multiply V — 2 QB extra MFMAs per tile (the pipe has slack) instead of 16 QB v_add
+    // and the final cross-group sum
+    f32x4 lacc[QB];
+    float m[QB];
+    const frag_t ones = Mma16<T>::ones();
 #pragma unroll
-    for (int d = 0; d < A::NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int d = 0; d < A::NDB; ++d) o[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[qb] = -INFINITY;
+    }
 
     const int ntiles = (N + KT - 1) / KT;
     TileStage<T, DH> sk, sv;
-    tile_load<T, DH>(sk, kbase, rs, 0, N, tid);
-    tile_load<T, DH>(sv, vbase, rs, 0, N, tid);
+    auto load = [&](int t) {
+        tile_load<T, DH>(sk, kbase, rs, t * KT, N, tid);
+        tile_load<T, DH>(sv, vbase, rs, t * KT, N, tid);
+    };
+    ST::prime(smem, ntiles, sk, sv, tid, load);
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        tile_store<T, DH>(sk, ldsK, tid);
-        tile_store<T, DH>(sv, ldsV, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
-            tile_load<T, DH>(sk, kbase, rs, (kt + 1) * KT, N, tid);
-            tile_load<T, DH>(sv, vbase, rs, (kt + 1) * KT, N, tid);
-        }
-        // Sᵀ[key][q] for the tile's 4 key blocks
-        f32x4 s[4];
+        const char* ldsK = ST::begin(smem, kt, ntiles, sk, sv, tid, load);
+        const char* ldsV = ldsK + A::TILE_BYTES;
+        // Sᵀ[key][q] for the tile's 4 key blocks: each K fragment feeds the QB query blocks
+        f32x4 s[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < A::NCH; ++c) Mma16<T>::mma(s[kb], frag_row<T, DH>(ldsK, kb, c, lane), qf[c]);
-        }
-        float mx = -INFINITY;
+            for (int qb = 0; qb < QB; ++qb) s[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+            for (int c = 0; c < A::NCH; ++c) {
+                const frag_t kf = frag_row<T, DH>(ldsK, kb, c, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * KT + kb * 16 + 4 * g + r;
-                const float t = key < N ? s[kb][r] * scale_log2e : -INFINITY;
-                s[kb][r] = t;
-                mx = fmaxf(mx, t);
+                for (int qb = 0; qb < QB; ++qb) Mma16<T>::mma(s[qb][kb], kf, qf[qb][c]);
             }
-        const float m_new = fmaxf(m, group_max(mx));  // finite: every tile holds at least one valid key
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-                s[kb][r] = p;
-                psum += p;
-            }
-        l = l * alpha + psum;
-        m = m_new;
-#pragma unroll
-        for (int d = 0; d < A::NDB; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
-        // Oᵀ[d][q] += Vᵀ[d][key] · Pᵀ[key][q]
-#pragma unroll
-        for (int rc = 0; rc < A::NRC; ++rc) {
-            const frag_t pf = frag_from_acc<T>(s, rc);
-#pragma unroll
-            for (int d = 0; d < A::NDB; ++d) Mma16<T>::mma(o[d], frag_tr<T, DH>(ldsV, rc, d, lane), pf);
         }
+        const bool ragged = (kt + 1) * KT > N;          // only the last tile can hold keys beyond N
+        frag_t pf[QB][A::NRC];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (__builtin_expect(ragged, 0)) {
+                asm volatile("" ::: "memory");          // keep this a branch: as selects it costs 64 VALU instructions in EVERY tile
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * KT + kb * 16 + 4 * g + r >= N) s[qb][kb][r] = -INFINITY;
+            }
+            // running maximum in units of log2: the scale is positive, so max(scale * s) = scale * max(s)
+            float mx = max3f(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+            mx = max3f(mx, s[qb][0][3], s[qb][1][0]);
+            mx = max3f(mx, s[qb][1][1], s[qb][1][2]);
+            mx = max3f(mx, s[qb][1][3], s[qb][2][0]);
+            mx = max3f(mx, s[qb][2][1], s[qb][2][2]);
+            mx = max3f(mx, s[qb][2][3], s[qb][3][0]);
+            mx = max3f(mx, s[qb][3][1], s[qb][3][2]);
+            mx = fmaxf(mx, s[qb][3][3]);
+            const float m_new = fmaxf(m[qb], group_max(mx) * scale_log2e);  // finite: every tile holds at least one valid key
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[qb][kb][r] = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][r], scale_log2e, -m_new));
+            if (__any(m_new > m[qb])) {                 // exact: where no row's maximum moved the factor is exp2(0) = 1
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
+#pragma unroll
+                for (int d = 0; d < A::NDB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][d][r] *= alpha;
+                m[qb] = m_new;
+            }
+#pragma unroll
+            for (int rc = 0; rc < A::NRC; ++rc) {
+                pf[qb][rc] = frag_from_acc<T>(s[qb], rc);
+                Mma16<T>::mma(lacc[qb], ones, pf[qb][rc]);
+            }
+        }
+        // Oᵀ[d][q] += Vᵀ[d][key] · Pᵀ[key][q]: each Vᵀ fragment feeds the QB query blocks
+#pragma unroll
+        for (int rc = 0; rc < A::NRC; ++rc)
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) {
+                const frag_t vf = frag_tr<T, DH>(ldsV, rc, d, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) Mma16<T>::mma(o[qb][d], vf, pf[qb][rc]);
+            }
+        ST::end();
     }
-    const float lt = group_sum(l);
-    if (q < N) {
-        const float inv = 1.f / lt;
-        T* op = out + (b * N + q) * D + h * DH;
 #pragma unroll
-        for (int d = 0; d < A::NDB; ++d) {
-            Vec4<T> v;
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lt = lacc[qb][0];          // every accumulator row holds the full row sum of its query column
+        const int q = q0 + 16 * qb;
+        if (q < N) {
+            const float inv = 1.f / lt;
+            T* op = out + (b * N + q) * D + h * DH;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v.set(r, o[d][r] * inv);
-            *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            for (int d = 0; d < A::NDB; ++d) {
+                Vec4<T> v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v.set(r, o[qb][d][r] * inv);
+                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            }
+            if (g == 0) lse[(b * H + h) * N + q] = m[qb] + log2f(lt);
         }
-        if (g == 0) lse[(b * H + h) * N + q] = m + log2f(lt);
     }
 }
 
@@ -291,15 +387,14 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
 // ===================================================================================================
 // backward, dQ: query on the lane, loop over key tiles
 // ===================================================================================================
-template <typename T, int DH>
+template <typename T, int DH, int QB, int NBUF>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   T* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
     typedef AT<T, DH> A;
     typedef typename A::frag_t frag_t;
+    typedef Stream<T, DH, NBUF> ST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsK = smem;
-    char* ldsV = smem + A::TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
@@ -309,66 +404,91 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
     const T* kbase = qbase + D;
     const T* vbase = qbase + 2 * D;
     const T* dobase = dout + b * N * (int64_t)D + h * DH;
-    const int q = blockIdx.x * 64 + wave * 16 + li;
+    const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB) + li;
 
-    frag_t qf[A::NCH], dof[A::NCH];
+    frag_t qf[QB][A::NCH], dof[QB][A::NCH];
+    float my_lse[QB], my_delta[QB];
+    f32x4 dq[QB][A::NDB];
 #pragma unroll
-    for (int c = 0; c < A::NCH; ++c) {
-        qf[c] = frag_global<T, DH>(qbase, rs, q, N, c, lane);
-        dof[c] = frag_global<T, DH>(dobase, D, q, N, c, lane);
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + 16 * qb;
+#pragma unroll
+        for (int c = 0; c < A::NCH; ++c) {
+            qf[qb][c] = frag_global<T, DH>(qbase, rs, q, N, c, lane);
+            dof[qb][c] = frag_global<T, DH>(dobase, D, q, N, c, lane);
+        }
+        my_lse[qb] = q < N ? lse[(b * H + h) * N + q] : 0.f;
+        my_delta[qb] = q < N ? delta[(b * H + h) * N + q] : 0.f;
+#pragma unroll
+        for (int d = 0; d < A::NDB; ++d) dq[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float my_lse = q < N ? lse[(b * H + h) * N + q] : 0.f;
-    const float my_delta = q < N ? delta[(b * H + h) * N + q] : 0.f;
-
-    f32x4 dq[A::NDB];
-#pragma unroll
-    for (int d = 0; d < A::NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (N + KT - 1) / KT;
     TileStage<T, DH> sk, sv;
-    tile_load<T, DH>(sk, kbase, rs, 0, N, tid);
-    tile_load<T, DH>(sv, vbase, rs, 0, N, tid);
+    auto load = [&](int t) {
+        tile_load<T, DH>(sk, kbase, rs, t * KT, N, tid);
+        tile_load<T, DH>(sv, vbase, rs, t * KT, N, tid);
+    };
+    ST::prime(smem, ntiles, sk, sv, tid, load);
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        tile_store<T, DH>(sk, ldsK, tid);
-        tile_store<T, DH>(sv, ldsV, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {
-            tile_load<T, DH>(sk, kbase, rs, (kt + 1) * KT, N, tid);
-            tile_load<T, DH>(sv, vbase, rs, (kt + 1) * KT, N, tid);
-        }
-        f32x4 ds[4];
+        const char* ldsK = ST::begin(smem, kt, ntiles, sk, sv, tid, load);
+        const char* ldsV = ldsK + A::TILE_BYTES;
+        f32x4 ds[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 s[QB], dp[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int c = 0; c < A::NCH; ++c) {
-                Mma16<T>::mma(s, frag_row<T, DH>(ldsK, kb, c, lane), qf[c]);    // Sᵀ[key][q]
-                Mma16<T>::mma(dp, frag_row<T, DH>(ldsV, kb, c, lane), dof[c]);  // dPᵀ[key][q]
-            }
+                const frag_t kf = frag_row<T, DH>(ldsK, kb, c, lane), vf = frag_row<T, DH>(ldsV, kb, c, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * KT + kb * 16 + 4 * g + r;
-                const float p = key < N ? __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -my_lse)) : 0.f;
-                ds[kb][r] = p * (dp[r] - my_delta);
+                for (int qb = 0; qb < QB; ++qb) {
+                    Mma16<T>::mma(s[qb], kf, qf[qb][c]);     // Sᵀ[key][q]
+                    Mma16<T>::mma(dp[qb], vf, dof[qb][c]);   // dPᵀ[key][q]
+                }
             }
+            // keys beyond N need no mask here: their K rows were zero-filled by tile_load, so whatever dS they get multiplies zeros in
+            // dQ += dS K (and it is finite: S = dP = 0 for them)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -my_lse[qb]));
+                    ds[qb][kb][r] = p * (dp[qb][r] - my_delta[qb]);
+                }
         }
         // dQᵀ[d][q] += Kᵀ[d][key] · dSᵀ[key][q]
+        frag_t f[QB][A::NRC];
 #pragma unroll
-        for (int rc = 0; rc < A::NRC; ++rc) {
-            const frag_t f = frag_from_acc<T>(ds, rc);
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-            for (int d = 0; d < A::NDB; ++d) Mma16<T>::mma(dq[d], frag_tr<T, DH>(ldsK, rc, d, lane), f);
-        }
+            for (int rc = 0; rc < A::NRC; ++rc) f[qb][rc] = frag_from_acc<T>(ds[qb], rc);
+#pragma unroll
+        for (int rc = 0; rc < A::NRC; ++rc)
+#pragma unroll
+            for (int d = 0; d < A::NDB; ++d) {
+                const frag_t kt_f = frag_tr<T, DH>(ldsK, rc, d, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) Mma16<T>::mma(dq[qb][d], kt_f, f[qb][rc]);
+            }
+        ST::end();
     }
-    if (q < N) {
-        T* op = dqkv + (b * N + q) * rs + h * DH;
 #pragma unroll
-        for (int d = 0; d < A::NDB; ++d) {
-            Vec4<T> v;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + 16 * qb;
+        if (q < N) {
+            T* op = dqkv + (b * N + q) * rs + h * DH;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v.set(r, dq[d][r] * scale);
-            *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            for (int d = 0; d < A::NDB; ++d) {
+                Vec4<T> v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v.set(r, dq[qb][d][r] * scale);
+                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+            }
         }
     }
 }
@@ -376,17 +496,16 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
 // ===================================================================================================
 // backward, dK / dV: key on the lane, loop over query tiles
 // ===================================================================================================
-template <typename T, int DH>
+template <typename T, int DH, int QB, int NBUF>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                                    T* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
     typedef AT<T, DH> A;
     typedef typename A::frag_t frag_t;
+    typedef Stream<T, DH, NBUF> ST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsQ = smem;
-    char* ldsDO = smem + A::TILE_BYTES;
-    float* ldsLse = reinterpret_cast<float*>(smem + 2 * A::TILE_BYTES);  // [64]
-    float* ldsDelta = ldsLse + KT;                                       // [64]
+    // per-query constants of the streamed tile, one [2][64] float pair per pipeline buffer, behind the tile buffers
+    float* ldsRow = reinterpret_cast<float*>(smem + NBUF * ST::PAIR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
@@ -398,83 +517,158 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
     const T* dobase = dout + b * N * (int64_t)D + h * DH;
     const float* lse_bh = lse + (b * H + h) * N;
     const float* delta_bh = delta + (b * H + h) * N;
-    const int key = blockIdx.x * 64 + wave * 16 + li;
+    const int key0 = blockIdx.x * (64 * QB) + wave * (16 * QB) + li;
 
-    frag_t kf[A::NCH], vf[A::NCH];
+    frag_t kf[QB][A::NCH], vf[QB][A::NCH];
+    f32x4 dk[QB][A::NDB], dv[QB][A::NDB];
 #pragma unroll
-    for (int c = 0; c < A::NCH; ++c) {
-        kf[c] = frag_global<T, DH>(kbase, rs, key, N, c, lane);
-        vf[c] = frag_global<T, DH>(vbase, rs, key, N, c, lane);
-    }
-    f32x4 dk[A::NDB], dv[A::NDB];
+    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-    for (int d = 0; d < A::NDB; ++d) {
-        dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < A::NCH; ++c) {
+            kf[qb][c] = frag_global<T, DH>(kbase, rs, key0 + 16 * qb, N, c, lane);
+            vf[qb][c] = frag_global<T, DH>(vbase, rs, key0 + 16 * qb, N, c, lane);
+        }
+#pragma unroll
+        for (int d = 0; d < A::NDB; ++d) {
+            dk[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     const int ntiles = (N + KT - 1) / KT;
     TileStage<T, DH> sq, sdo;
-    tile_load<T, DH>(sq, qbase, rs, 0, N, tid);
-    tile_load<T, DH>(sdo, dobase, D, 0, N, tid);
-    for (int qt = 0; qt < ntiles; ++qt) {
-        __syncthreads();
-        tile_store<T, DH>(sq, ldsQ, tid);
-        tile_store<T, DH>(sdo, ldsDO, tid);
+    float r_lse = 0.f, r_delta = 0.f;       // threads 0-63: constants of the register tile's queries
+    auto load = [&](int t) {
+        tile_load<T, DH>(sq, qbase, rs, t * KT, N, tid);
+        tile_load<T, DH>(sdo, dobase, D, t * KT, N, tid);
         if (tid < KT) {
-            const int qq = qt * KT + tid;
-            ldsLse[tid] = qq < N ? lse_bh[qq] : INFINITY;  // +inf -> P = 0 for padding queries
-            ldsDelta[tid] = qq < N ? delta_bh[qq] : 0.f;
+            const int qq = t * KT + tid;
+            r_lse = qq < N ? lse_bh[qq] : INFINITY;      // +inf -> P = 0 for padding queries
+            r_delta = qq < N ? delta_bh[qq] : 0.f;
         }
+    };
+    // the row constants travel with their tile: written to LDS where the tile is written
+    if constexpr (NBUF == 2) {
+        load(0);
+        tile_store<T, DH>(sq, smem, tid);
+        tile_store<T, DH>(sdo, smem + A::TILE_BYTES, tid);
+        if (tid < KT) {
+            ldsRow[tid] = r_lse;
+            ldsRow[KT + tid] = r_delta;
+        }
+        if (ntiles > 1) load(1);
         __syncthreads();
-        if (qt + 1 < ntiles) {
-            tile_load<T, DH>(sq, qbase, rs, (qt + 1) * KT, N, tid);
-            tile_load<T, DH>(sdo, dobase, D, (qt + 1) * KT, N, tid);
+    } else {
+        load(0);
+    }
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const char* ldsQ;
+        const float* rowc;
+        if constexpr (NBUF == 2) {
+            ldsQ = smem + (qt & 1) * ST::PAIR;
+            rowc = ldsRow + (qt & 1) * 2 * KT;
+            if (qt + 1 < ntiles) {
+                char* nxt = smem + ((qt + 1) & 1) * ST::PAIR;
+                tile_store<T, DH>(sq, nxt, tid);
+                tile_store<T, DH>(sdo, nxt + A::TILE_BYTES, tid);
+                if (tid < KT) {
+                    float* rn = ldsRow + ((qt + 1) & 1) * 2 * KT;
+                    rn[tid] = r_lse;
+                    rn[KT + tid] = r_delta;
+                }
+                if (qt + 2 < ntiles) load(qt + 2);
+            }
+        } else {
+            __syncthreads();
+            tile_store<T, DH>(sq, smem, tid);
+            tile_store<T, DH>(sdo, smem + A::TILE_BYTES, tid);
+            if (tid < KT) {
+                ldsRow[tid] = r_lse;
+                ldsRow[KT + tid] = r_delta;
+            }
+            __syncthreads();
+            if (qt + 1 < ntiles) load(qt + 1);
+            ldsQ = smem;
+            rowc = ldsRow;
         }
-        f32x4 pm[4], ds[4];
+        const char* ldsDO = ldsQ + A::TILE_BYTES;
+        f32x4 pm[QB][4], ds[QB][4];
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        for (int tb = 0; tb < 4; ++tb) {      // 16-query blocks of the streamed tile
+            f32x4 s[QB], dp[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int c = 0; c < A::NCH; ++c) {
-                Mma16<T>::mma(s, frag_row<T, DH>(ldsQ, qb, c, lane), kf[c]);     // S[q][key]
-                Mma16<T>::mma(dp, frag_row<T, DH>(ldsDO, qb, c, lane), vf[c]);   // dP[q][key]
-            }
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsLse + qb * 16 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
+                const frag_t qfr = frag_row<T, DH>(ldsQ, tb, c, lane), dofr = frag_row<T, DH>(ldsDO, tb, c, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -l4[r]));
-                pm[qb][r] = p;
-                ds[qb][r] = p * (dp[r] - d4[r]);
+                for (int qb = 0; qb < QB; ++qb) {
+                    Mma16<T>::mma(s[qb], qfr, kf[qb][c]);      // S[q][key]
+                    Mma16<T>::mma(dp[qb], dofr, vf[qb][c]);    // dP[q][key]
+                }
             }
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(rowc + tb * 16 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(rowc + KT + tb * 16 + 4 * g);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][r], scale_log2e, -l4[r]));
+                    pm[qb][tb][r] = p;
+                    ds[qb][tb][r] = p * (dp[qb][r] - d4[r]);
+                }
         }
+        frag_t fp[QB][A::NRC], fs[QB][A::NRC];
 #pragma unroll
-        for (int rc = 0; rc < A::NRC; ++rc) {
-            const frag_t fp = frag_from_acc<T>(pm, rc);
-            const frag_t fs = frag_from_acc<T>(ds, rc);
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int rc = 0; rc < A::NRC; ++rc) {
+                fp[qb][rc] = frag_from_acc<T>(pm[qb], rc);
+                fs[qb][rc] = frag_from_acc<T>(ds[qb], rc);
+            }
+#pragma unroll
+        for (int rc = 0; rc < A::NRC; ++rc)
 #pragma unroll
             for (int d = 0; d < A::NDB; ++d) {
-                Mma16<T>::mma(dv[d], frag_tr<T, DH>(ldsDO, rc, d, lane), fp);  // dVᵀ[d][key] += dOᵀ[d][q]·P[q][key]
-                Mma16<T>::mma(dk[d], frag_tr<T, DH>(ldsQ, rc, d, lane), fs);   // dKᵀ[d][key] += Qᵀ[d][q]·dS[q][key]
+                const frag_t dot = frag_tr<T, DH>(ldsDO, rc, d, lane), qt_f = frag_tr<T, DH>(ldsQ, rc, d, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    Mma16<T>::mma(dv[qb][d], dot, fp[qb][rc]);   // dVᵀ[d][key] += dOᵀ[d][q]·P[q][key]
+                    Mma16<T>::mma(dk[qb][d], qt_f, fs[qb][rc]);  // dKᵀ[d][key] += Qᵀ[d][q]·dS[q][key]
+                }
             }
-        }
+        ST::end();
     }
-    if (key < N) {
-        T* kp = dqkv + (b * N + key) * rs + D + h * DH;
-        T* vp = kp + D;
 #pragma unroll
-        for (int d = 0; d < A::NDB; ++d) {
-            Vec4<T> a, c;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int key = key0 + 16 * qb;
+        if (key < N) {
+            T* kp = dqkv + (b * N + key) * rs + D + h * DH;
+            T* vp = kp + D;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                a.set(r, dk[d][r] * scale);
-                c.set(r, dv[d][r]);
+            for (int d = 0; d < A::NDB; ++d) {
+                Vec4<T> a, c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a.set(r, dk[qb][d][r] * scale);
+                    c.set(r, dv[qb][d][r]);
+                }
+                *reinterpret_cast<Vec4<T>*>(kp + d * 16 + 4 * g) = a;
+                *reinterpret_cast<Vec4<T>*>(vp + d * 16 + 4 * g) = c;
             }
-            *reinterpret_cast<Vec4<T>*>(kp + d * 16 + 4 * g) = a;
-            *reinterpret_cast<Vec4<T>*>(vp + d * 16 + 4 * g) = c;
         }
     }
 }
+
+// geometry of the streaming kernels per element type: bf16 takes two 16-row blocks per wave and two LDS buffers per stream
+template <typename T, int DH> struct Geo {
+    static constexpr int QB = sizeof(T) == 2 ? 2 : 1;
+    static constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;
+    static constexpr size_t SMEM = (size_t)NBUF * 2 * AT<T, DH>::TILE_BYTES;
+    static constexpr size_t SMEM_DKV = SMEM + (size_t)NBUF * 2 * KT * sizeof(float);
+};
 
 template <typename K> int allow_big_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return UCFVIT_OK;
@@ -488,11 +682,11 @@ template <typename K> int allow_big_lds(K kernel, size_t bytes) {
 
 template <typename T, int DH>
 int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)H, (unsigned)B);
-    constexpr size_t smem_fwd = 2 * AT<T, DH>::TILE_BYTES;
-    if (int rc = allow_big_lds(attn_fwd_kernel<T, DH>, smem_fwd)) return rc;
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(AT_THREADS), smem_fwd, s, (const T*)qkv, (T*)out, lse, (int)N,
-                       (int)H, scale * 1.44269504088896340736f);
+    typedef Geo<T, DH> G;
+    const dim3 grid((unsigned)((N + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)H, (unsigned)B);
+    auto kern = attn_fwd_kernel<T, DH, G::QB, G::NBUF>;
+    if (int rc = allow_big_lds(kern, G::SMEM)) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(AT_THREADS), G::SMEM, s, (const T*)qkv, (T*)out, lse, (int)N, (int)H, scale * 1.44269504088896340736f);
     UCF_LAUNCH_CHECK("ucfvit_attention_fwd");
     return UCFVIT_OK;
 }
@@ -507,21 +701,22 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;
     }
+    typedef Geo<T, DH> G;
     const int64_t nd = B * N * H * (DH / (16 / (int64_t)sizeof(T)));
     hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, B,
                        (int)N, (int)H);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)H, (unsigned)B);
+    const dim3 grid((unsigned)((N + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)H, (unsigned)B);
     const float sl2 = scale * 1.44269504088896340736f;
-    constexpr size_t smem_dq = 2 * AT<T, DH>::TILE_BYTES;
-    constexpr size_t smem_dkv = smem_dq + 2 * KT * sizeof(float);
-    if (int rc = allow_big_lds(attn_bwd_dq_kernel<T, DH>, smem_dq)) return rc;
-    if (int rc = allow_big_lds(attn_bwd_dkv_kernel<T, DH>, smem_dkv)) return rc;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), grid, dim3(AT_THREADS), smem_dq, s, (const T*)qkv, (const T*)dout, lse,
-                       (const float*)delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
+    auto k_dq = attn_bwd_dq_kernel<T, DH, G::QB, G::NBUF>;
+    auto k_dkv = attn_bwd_dkv_kernel<T, DH, G::QB, G::NBUF>;
+    if (int rc = allow_big_lds(k_dq, G::SMEM)) return rc;
+    if (int rc = allow_big_lds(k_dkv, G::SMEM_DKV)) return rc;
+    hipLaunchKernelGGL(k_dq, grid, dim3(AT_THREADS), G::SMEM, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta, (T*)dqkv, (int)N,
+                       (int)H, scale, sl2);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(dq)");
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), grid, dim3(AT_THREADS), smem_dkv, s,
-                       (const T*)qkv, (const T*)dout, lse, (const float*)delta, (T*)dqkv, (int)N, (int)H, scale, sl2);
+    hipLaunchKernelGGL(k_dkv, grid, dim3(AT_THREADS), G::SMEM_DKV, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta, (T*)dqkv,
+                       (int)N, (int)H, scale, sl2);
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(dkv)");
     return UCFVIT_OK;
 }
