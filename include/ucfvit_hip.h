@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 6
+#define UCFVIT_ABI_VERSION 7
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -48,6 +48,11 @@ const char* ucfvit_last_error(void);
  * bench.py: the rate is the ceiling the chip's clock / power management leaves to any bf16 MFMA kernel on that device.
  * sink: >= 256 floats of device memory (never written in practice). */
 int64_t ucfvit_mfma_probe(float* sink, int iters, void* stream);
+
+/* Diagnostic (no reference counterpart): `workgroups` workgroups that each hold one CU (512 threads, 96 KiB LDS) for about `microseconds`,
+ * doing nothing — a stand-in for a collective's kernel next to the persistent GEMM grids on a one-GPU box (tools/gemm_contention.py).
+ * sink: >= 512 floats of device memory (never written). */
+int ucfvit_occupy(int workgroups, int microseconds, float* sink, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:  C[M,N] = epilogue( alpha * op(A)[M,K] · op(B)[K,N] )
@@ -100,7 +105,14 @@ typedef struct ucfvit_gemm_desc {
                               * C (taken in fp32 before the rounding to dtype): fp32 [ucfvit_gemm_colsum_rows(desc)][N], every entry
                               * written.  Summed over its rows (ucfvit_reduce_rows) it is the bias gradient of the Linear layer whose
                               * output gradient this GEMM produces (fc1: C = dh), so dh is not read again by ucfvit_colsum.  NULL: off. */
+    void* sched_state;       /* optional: UCFVIT_GEMM_SCHED_BYTES of device memory, 16-byte aligned, zeroed ONCE by the caller and then
+                              * used by every launch of ONE stream.  With it the persistent 256x256 kernel hands its output tiles out through
+                              * device-scope atomic counters (work-conserving when another kernel — an RCCL collective overlapping backward —
+                              * holds some of the CUs: workgroups that start late find the list empty instead of owning a share of it) and
+                              * leaves the state zeroed.  Results do not depend on it (every tile is computed by one workgroup either way).
+                              * NULL: static tile order. */
 } ucfvit_gemm_desc;
+#define UCFVIT_GEMM_SCHED_BYTES 1024
 
 /* bytes of workspace the split-K path would use for this problem (0: none).  Without it the GEMM still runs, un-split. */
 int64_t ucfvit_gemm_workspace(const ucfvit_gemm_desc* desc);

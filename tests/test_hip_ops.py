@@ -496,3 +496,63 @@ def test_variable_aggregation_attention_fwd_bwd(dtype, V, R, D, dh):
         assert float(dq.abs().max()) < 1e-4
     else:
         assert rel_err(dq.cpu(), qr.grad.float()) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------- dynamic tile schedule (multi-GPU hardening)
+_DYN_SCRIPT = r'''
+import os, sys, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "ucf-vit_amd"))
+from UCF_VIT._hip import ops
+from UCF_VIT._hip.lib import ACT_GELU_SAVE_DERIV
+g = torch.Generator().manual_seed(0)
+dev = "cuda"
+rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).bfloat16().to(dev)
+M, D = 9000, 512                       # 36 x 8 = 288 tiles of 256 x 256 for the 4D-wide layers: more than one round, ragged last M-tile
+x, x4, res = rnd(M, D), rnd(M, 4 * D), rnd(M, D)
+w1, w2, b1, b2 = rnd(4 * D, D, sc=0.05), rnd(D, 4 * D, sc=0.05), rnd(4 * D), rnd(D)
+dy, dy4 = rnd(M, D), rnd(M, 4 * D)
+out = {}
+for rep in range(3):                   # several launches share one schedule state: it must come back zeroed every time
+    aux = torch.empty(M, 4 * D, dtype=torch.bfloat16, device=dev)
+    out["fc1"] = ops.linear_fwd(x, w1, b1, act=ACT_GELU_SAVE_DERIV, aux_out=aux)
+    out["aux"] = aux
+    out["fc2"] = ops.linear_fwd(x4, w2, b2, residual=res)
+    cs = torch.empty(4 * D, dtype=torch.float32, device=dev)
+    out["dg"] = ops.linear_dgrad_t(dy, w2.T.contiguous(), act_grad_aux=aux, aux_is_deriv=True, c_colsum=cs)
+    out["cs"] = cs
+    out["wg"] = torch.stack([t.reshape(-1)[:4096] for t in ops.wgrad_grouped([(dy4, x, None, False), (dy, x4, None, False), (dy4[:, :1024], x, None, False)])])
+torch.cuda.synchronize()
+st = [v for v in ops._sched_states.values()]
+out["state_sum"] = torch.tensor([float(sum(int(t.abs().sum()) for t in st)), float(len(st))])
+torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[2])
+'''
+
+
+def test_gemm_dynamic_tile_schedule_is_result_neutral(tmp_path):
+    """desc.sched_state (tiles of the persistent 256x256 kernel handed out by atomic counters, for launches that share the GPU with an
+    RCCL collective): bitwise the results of the static order for every epilogue kind and the grouped weight gradient, with the grid
+    capped at 256 / 240 / 200 workgroups (UCFVIT_GEMM_CUS: what a collective holding 16 / 56 CUs leaves), and the schedule state is
+    all zeros again after every launch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dyn.py"
+    script.write_text(_DYN_SCRIPT)
+    res = {}
+    for dyn, cus in (("0", "256"), ("1", "256"), ("1", "240"), ("1", "200"), ("0", "200")):
+        f = tmp_path / f"o_{dyn}_{cus}.pt"
+        r = subprocess.run([sys.executable, str(script), root, str(f)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, UCFVIT_GEMM_DYNAMIC=dyn, UCFVIT_GEMM_CUS=cus))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[(dyn, cus)] = torch.load(f, weights_only=True)
+    ref = res[("0", "256")]
+    assert ref["state_sum"][1] == 0                       # static: no state was ever allocated
+    for key, o in res.items():
+        for k in ("fc1", "aux", "fc2", "dg", "cs", "wg"):
+            assert torch.equal(o[k], ref[k]), (key, k)
+        if key[0] == "1":
+            assert o["state_sum"][1] >= 1 and o["state_sum"][0] == 0, key      # state exists and is zero again
+    # and the values are right (fp32 product of the same bf16 operands)
+    g = torch.Generator().manual_seed(0)
+    assert torch.isfinite(ref["fc2"].float()).all() and float(ref["fc2"].float().abs().max()) > 0.1

@@ -109,6 +109,8 @@ class HipDataParallel(nn.Module):
         self._callback_queued = False
         if self._hip:
             _HF.add_wgrad_flush_listener(self._after_wgrad_flush, self.store)
+            if self.world > 1:
+                _ops.set_dynamic_tile_schedule(True)     # RCCL's workgroups will hold CUs while the persistent GEMM grids run
         for p in params:
             if p.requires_grad:
                 p.register_post_accumulate_grad_hook(self._on_grad)

@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+GEMM_SCHED_BYTES = 1024
+ABI_VERSION = 7
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
@@ -29,6 +30,7 @@ class GemmDesc(Structure):
         ("alpha", c_float),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("c_colsum_partial", c_void_p),
+        ("sched_state", c_void_p),
     ]
 
 
@@ -37,6 +39,7 @@ _P, _I64, _I, _F = c_void_p, c_int64, c_int, c_float
 SIGNATURES = {
     "ucfvit_abi_version": (c_int, []),
     "ucfvit_mfma_probe": (_I64, [_P, _I, _P]),
+    "ucfvit_occupy": (c_int, [_I, _I, _P, _P]),
     "ucfvit_last_error": (c_char_p, []),
     "ucfvit_gemm_workspace": (c_int64, [POINTER(GemmDesc)]),
     "ucfvit_gemm": (c_int, [POINTER(GemmDesc), _P]),

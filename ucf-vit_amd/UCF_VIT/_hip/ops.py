@@ -53,6 +53,32 @@ def workspace(nbytes, device):
     return ws
 
 
+# Dynamic tile schedule of the persistent GEMM (desc.sched_state, include/ucfvit_hip.h): off for a single process (every CU is the GEMM's,
+# the static order costs nothing), switched on by HipDataParallel / the tensor-parallel blocks, whose collectives hold CUs while GEMMs run.
+# UCFVIT_GEMM_DYNAMIC=1|0 forces it.  One state block per (device, stream): launches of one stream are ordered, so they can share it.
+_dynamic_sched = os.environ.get("UCFVIT_GEMM_DYNAMIC", "") == "1"
+_sched_states = {}
+
+
+def set_dynamic_tile_schedule(on):
+    global _dynamic_sched
+    if os.environ.get("UCFVIT_GEMM_DYNAMIC", "") in ("0", "1"):
+        return _dynamic_sched                      # forced by the environment
+    _dynamic_sched = bool(on)
+    return _dynamic_sched
+
+
+def _sched_state(device):
+    if not _dynamic_sched:
+        return None
+    key = (device.index, _stream())
+    st = _sched_states.get(key)
+    if st is None:
+        st = torch.zeros(_l.GEMM_SCHED_BYTES // 4, dtype=torch.int32, device=device)     # zeroed once; every launch leaves it zeroed
+        _sched_states[key] = st
+    return st.data_ptr()
+
+
 def mfma_probe(iters=10000):
     """diagnostic: one launch of a pure bf16 MFMA stream on the current stream; returns the FLOPs it executes"""
     L = _l.load()
@@ -88,6 +114,7 @@ def gemm(A, B, M, N, K, a_layout, b_layout, out=None, out_dtype=None, bias=None,
     d.act, d.accumulate, d.alpha = act, 1 if accumulate else 0, alpha
     d.workspace, d.workspace_bytes = None, 0
     d.c_colsum_partial = None
+    d.sched_state = _sched_state(A.device)
     cs_rows, cs_part = 0, None
     if c_colsum is not None:
         _chk(c_colsum, "gemm.c_colsum")
@@ -134,6 +161,8 @@ def wgrad_grouped(items):
         d.dtype, d.out_dtype = dt(dy2), F32
         d.act, d.accumulate, d.alpha = ACT_NONE, 1 if acc else 0, 1.0
         d.workspace, d.workspace_bytes = None, 0
+        d.c_colsum_partial = None
+        d.sched_state = _sched_state(dy2.device)
     _l.check(L.ucfvit_gemm_grouped(arr, n, _stream()), "ucfvit_gemm_grouped")
     return outs
 

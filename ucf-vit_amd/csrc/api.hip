@@ -56,3 +56,39 @@ extern "C" int64_t ucfvit_mfma_probe(float* sink, int iters, void* stream) {
     UCF_LAUNCH_CHECK("ucfvit_mfma_probe");
     return (int64_t)grid * 4 * ((iters + 1) / 2 * 2) * 16 * (2ll * 16 * 16 * 32);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Diagnostic: hold `workgroups` CUs for about `microseconds` (one 512-thread workgroup with 96 KiB of LDS each: no GEMM workgroup fits
+// beside it) — what an RCCL collective does to the persistent GEMM grids when it overlaps backward.  On a one-GPU box this is how the
+// dynamic tile schedule (desc->sched_state) is measured against the static one (tools/gemm_contention.py).  The wait is bounded.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(512) void occupy_kernel(unsigned long long ticks, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char hold[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    unsigned spins = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && spins < (1u << 26)) {
+        __builtin_amdgcn_s_sleep(32);
+        ++spins;
+    }
+    if (spins == 0xFFFFFFFFu) sink[threadIdx.x] = hold[threadIdx.x];      // never true: keeps the LDS allocation referenced
+}
+}  // namespace
+
+extern "C" int ucfvit_occupy(int workgroups, int microseconds, float* sink, void* stream) {
+    UCF_CHECK_ARG(workgroups >= 1 && workgroups <= 256 && microseconds >= 1 && microseconds <= 1000000 && sink,
+                  "ucfvit_occupy: workgroups in 1..256, microseconds in 1..1e6, sink required");
+    static bool done = false;
+    constexpr int lds = 96 * 1024;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ucfvit_set_error("ucfvit_occupy: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+            return UCFVIT_ERR_HIP;
+        }
+        done = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(512), lds, (hipStream_t)stream, (unsigned long long)microseconds * 100ull, sink);
+    UCF_LAUNCH_CHECK("ucfvit_occupy");
+    return UCFVIT_OK;
+}

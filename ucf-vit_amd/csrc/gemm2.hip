@@ -129,7 +129,43 @@ struct Epi2 {
     float alpha;
     float* slab;       // split-K: fp32 partial matrices [splits][M][N] (ld = N); NULL when gridDim.y == 1
     float* cs_partial; // column sums of the output per 128-row block: [2 * tiles_m][N] (CS instantiations only), or NULL
+    unsigned* sched;   // dynamic tile schedule of the persistent 256x256 kernel (desc->sched_state), or NULL: static round-robin
 };
+
+// ---- dynamic tile schedule (gemm3_kernel) ------------------------------------------------------------------------------------------
+// A persistent grid with a STATIC tile list assumes every workgroup is resident from the start.  When another kernel holds some CUs —
+// an RCCL all-reduce overlapping backward — the workgroups that do not fit start only when a running one has finished its whole list,
+// and the launch takes twice as long.  With desc->sched_state the tiles are handed out by device-scope atomic counters instead: a
+// workgroup that starts late finds the list (nearly) empty and leaves; the resident ones have shared its tiles.  One counter per XCD
+// label (blockIdx.x & 7) and the same round / chunk geometry as the static order (xcd_remap), so the tiles an XCD works on at one time
+// still share operand panels.  A workgroup owns at most two tiles (the running one and the next, whose first K-tile it prefetches):
+// the draw for tile t + 1 is issued at the start of tile t - 1's epilogue and read at its end (nothing waits inside the K loop).
+// No workgroup ever waits for another one (no spins: nothing to deadlock).  The last workgroup to leave zeroes the counters, so the
+// state is ready for the next launch of the same stream; the caller zeroes it once, when it allocates it.
+constexpr int SCHED_XCD_STRIDE = 16;      // 32-bit words between the XCD counters (64 B: no two counters share a line)
+constexpr int SCHED_EXIT_WORD = 8 * SCHED_XCD_STRIDE;
+// tile-list position of the k-th draw of XCD label x (G = workgroups of the launch = tiles per round); -1: list exhausted
+__device__ __forceinline__ int sched_tile(unsigned k, int x, int G, int total) {
+    const int nf = (G - x + 7) >> 3;                 // positions of this label in a full round
+    const int full = total / G;
+    if (nf > 0 && k < (unsigned)(full * nf)) {
+        const int r = (int)k / nf, i = (int)k - r * nf;
+        return r * G + xcd_remap(i * 8 + x, G);
+    }
+    const int k2 = (int)k - full * nf, cnt = total - full * G;
+    if (k2 >= 0 && k2 < ((cnt - x + 7) >> 3)) return full * G + xcd_remap(k2 * 8 + x, cnt);
+    return -1;
+}
+__device__ __forceinline__ void sched_leave(unsigned* sched, int tid) {
+    if (tid == 0) {
+        const unsigned before = atomicAdd(sched + SCHED_EXIT_WORD, 1u);
+        if (before == gridDim.x - 1) {               // everybody else has left: nobody draws any more
+#pragma unroll
+            for (int x = 0; x < 8; ++x) sched[x * SCHED_XCD_STRIDE] = 0u;
+            sched[SCHED_EXIT_WORD] = 0u;
+        }
+    }
+}
 
 __device__ int g_band_override = 0;      // experiments: UCFVIT_GEMM_BAND=n forces the band width (0 = the rule below)
 
@@ -533,10 +569,31 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
         M_ = P.M; N_ = P.N; lda_ = P.lda; ldb_ = P.ldb; ldc_ = P.ldc; acc_ = P.accumulate;     \
         tile_origin((t_) - P.tile_start, P.tiles_m, P.tiles_n, BM, BN, m0_, n0_);              \
     } while (0)
+    const bool dyn = ep.sched != nullptr;                         // (launched with gridDim.y == 1 only)
+    const int xcd = blockIdx.x & 7;
+    int* sched_lds = reinterpret_cast<int*>(smem + 2 * BUF);      // 2 words behind the pipeline buffers (dynamic schedule only)
+    int t_next = -1;                                              // dynamic: tile-list position of the NEXT tile (-1: none)
     {
-        const int first = min(G, nwg);
-        if ((int)blockIdx.x >= first) return;
-        const int t0 = xcd_remap(blockIdx.x, first);
+        int t0;
+        if (dyn) {
+            if (tid == 0) {
+                unsigned* ctr = ep.sched + xcd * SCHED_XCD_STRIDE;
+                const int a = sched_tile(atomicAdd(ctr, 1u), xcd, G, nwg);
+                sched_lds[0] = a;
+                sched_lds[1] = a < 0 ? -1 : sched_tile(atomicAdd(ctr, 1u), xcd, G, nwg);
+            }
+            __syncthreads();
+            t0 = sched_lds[0];
+            t_next = sched_lds[1];
+            if (t0 < 0) {                                         // started late: the resident workgroups have taken every tile
+                sched_leave(ep.sched, tid);
+                return;
+            }
+        } else {
+            const int first = min(G, nwg);
+            if ((int)blockIdx.x >= first) return;
+            t0 = xcd_remap(blockIdx.x, first);
+        }
         PP_SELECT(t0, Ab, Bb, C, M, N, lda, ldb, ldc, accum, m0, n0);
     }
     float* slab = ep.slab ? ep.slab + (int64_t)blockIdx.y * M * N : nullptr;
@@ -563,16 +620,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
 
     for (int round = 0;; ++round) {
         int nm0 = 0, nn0 = 0;
-        const int next_base = (round + 1) * G;
-        const int next_cnt = min(G, nwg - next_base);
-        const bool has_next = (int)blockIdx.x < next_cnt;
+        if (!dyn) {
+            const int next_base = (round + 1) * G;
+            const int next_cnt = min(G, nwg - next_base);
+            t_next = (int)blockIdx.x < next_cnt ? next_base + xcd_remap(blockIdx.x, next_cnt) : -1;
+        }
+        const bool has_next = t_next >= 0;
         const char *nAb = Ab, *nBb = Bb;
         OutT* nC = C;
         int nM = M, nN = N, naccum = accum;
         int64_t nlda = lda, nldb = ldb, nldc = ldc;
         if (has_next) {
-            const int tn_ = next_base + xcd_remap(blockIdx.x, next_cnt);
-            PP_SELECT(tn_, nAb, nBb, nC, nM, nN, nlda, nldb, nldc, naccum, nm0, nn0);
+            PP_SELECT(t_next, nAb, nBb, nC, nM, nN, nlda, nldb, nldc, naccum, nm0, nn0);
         }
 
         f32x4 acc[FM][FN];
@@ -662,6 +721,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
 
         // ---- epilogue: staging area = the pipeline buffer of the K-tile just consumed ------------------------------------------
         float* stage = reinterpret_cast<float*>(smem + ((it - 1) & 1) * BUF) + wave * (16 * PADW);
+        // dynamic schedule: the draw for the tile after the next one goes out at the start of the epilogue and is read when it is done
+        unsigned drawn = 0u;
+        const bool draw = dyn && has_next && tid == 0;
+        if constexpr (EPI == EPI_GENERIC) {
+            if (draw) drawn = atomicAdd(ep.sched + xcd * SCHED_XCD_STRIDE, 1u);
+        }
         if constexpr (EPI != EPI_GENERIC) {
             static_assert(sizeof(OutT) == 2, "specialised epilogues write bf16");
             constexpr int NPASS = 16 / RPI;
@@ -670,6 +735,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
             // every DMA piece has been waited for by the asm waits above; a wait hipcc can see resets its bookkeeping (free: the
             // queue is empty), so the loads below get counted waits instead of vmcnt(0)
             __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) expcnt(7) lgkmcnt(15)
+            if (draw) drawn = atomicAdd(ep.sched + xcd * SCHED_XCD_STRIDE, 1u);
             Vec4<bf16> bias_v[FN];
             const bool has_bias = ep.bias != nullptr;
             if (has_bias) {
@@ -895,13 +961,16 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
         m0 = nm0;
         n0 = nn0;
         Ab = nAb; Bb = nBb; C = nC; M = nM; N = nN; accum = naccum; lda = nlda; ldb = nldb; ldc = nldc;
+        if (draw) sched_lds[0] = sched_tile(drawn, xcd, G, nwg);     // (one lane waits for its atomic here; the epilogue hid its latency)
         // the next tile's first K-tile was issued during the last K-tile and waited for (vmcnt(0) + barrier) at its end;
         // the epilogue's LDS staging of every wave must be finished before that buffer's partner is refilled:
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (dyn) t_next = sched_lds[0];      // written before the barrier; rewritten only behind the next tile's end-of-tile barrier
     }
+    if (dyn) sched_leave(ep.sched, tid);
 }
 
 // C[m][n] = alpha * sum_s slab[s][m][n] (+ C_old)   — fixed order, 16-B vectors
@@ -1054,7 +1123,7 @@ int launch2(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
 
 template <int LA, int LB, typename OutT, int EPI = EPI_GENERIC, bool CS = false, int NP = GROUP_MAX>
 int launch3g(const GroupsT<NP>& gt, int K, const Epi2& ep, int splits, int k_per_split, hipStream_t s) {
-    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128;
+    constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 16;      // + the two schedule words
     auto kern = gemm3_kernel<LA, LB, OutT, EPI, CS, NP>;
     static bool done = false;
     if (!done) {
@@ -1086,7 +1155,9 @@ int launch3g(const GroupsT<NP>& gt, int K, const Epi2& ep, int splits, int k_per
     int cap = cus / splits;
     if (cap < 1) cap = 1;
     const int gx = gt.total_tiles < cap ? gt.total_tiles : cap;
-    hipLaunchKernelGGL(kern, dim3(gx, splits), dim3(512), smem, s, gt, K, ep, k_per_split);
+    Epi2 epl = ep;
+    if (splits != 1) epl.sched = nullptr;       // K-slices walk their own tile lists: static order
+    hipLaunchKernelGGL(kern, dim3(gx, splits), dim3(512), smem, s, gt, K, epl, k_per_split);
     UCF_LAUNCH_CHECK("ucfvit_gemm(v3 ping-pong)");
     return UCFVIT_OK;
 }
@@ -1227,6 +1298,7 @@ int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     ep.alpha = d->alpha;
     ep.slab = nullptr;
     ep.cs_partial = nullptr;
+    ep.sched = (unsigned*)d->sched_state;
     if (d->c_colsum_partial) {
         if (colsum_rows_for(d) == 0 || !ucf_is_aligned16(d->c_colsum_partial)) {
             ucfvit_set_error("ucfvit_gemm: c_colsum_partial is not available for this problem (ask ucfvit_gemm_colsum_rows first)");
@@ -1294,6 +1366,7 @@ extern "C" int ucfvit_gemm_grouped(const ucfvit_gemm_desc* descs, int64_t n, voi
     Epi2 ep;
     memset(&ep, 0, sizeof(ep));
     ep.alpha = 1.0f;
+    ep.sched = (unsigned*)d0.sched_state;
     const int K = (int)d0.K;
     const int kps = ((K + BK2 - 1) / BK2) * BK2;
     const int la = d0.a_layout, lb = d0.b_layout;
