@@ -165,6 +165,22 @@ int ucfvit_attention_bwd(const void* qkv, const void* out, const void* dout, con
                          float* delta_ws, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
                          void* stream);
 
+/* Attention of a QUERY block against ANOTHER token block's keys / values: the building block of ring sequence parallelism (no reference
+ * counterpart: the reference constructs seq_par_group and asserts seq_par_size == 1, training_scripts/train_masked_fsdp.py:220).
+ *   q [B][Nq][ldq], k / v [B][Nk][ldkv] with head h at columns [h*dh, (h+1)*dh);  out [B][Nq][H*dh] (dtype), lse [B][H][Nq] in log2 units.
+ * Backward of one (query block, key block) pair of a softmax that spans several key blocks: `lse` is the log-sum-exp over ALL key blocks and
+ * `out` the final merged output (delta = rowsum(dO * O) is taken from them), so dq / dk / dv (fp32 [B][Nq|Nk][H*dh], += when accumulate)
+ * receive exactly this pair's terms.  delta_ws: B*H*Nq floats of scratch. */
+int ucfvit_attention_cross_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t Nq, int64_t Nk, int64_t H,
+                               int64_t dh, int64_t ldq, int64_t ldkv, float scale, int dtype, void* stream);
+int ucfvit_attention_cross_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, float* dq,
+                               float* dk, float* dv, float* delta_ws, int64_t B, int64_t Nq, int64_t Nk, int64_t H, int64_t dh, int64_t ldq,
+                               int64_t ldkv, float scale, int accumulate, int dtype, void* stream);
+/* online merge of partial results over disjoint key blocks: lse' = log2(2^lse_acc + 2^lse_part), o' = o_acc 2^(lse_acc - lse') +
+ * o_part 2^(lse_part - lse'); o_acc fp32 [B][Nq][H*dh], o_part dtype; first != 0: o_acc = o_part, lse_acc = lse_part */
+int ucfvit_attention_merge(float* o_acc, float* lse_acc, const void* o_part, const float* lse_part, int64_t B, int64_t Nq, int64_t H, int64_t dh,
+                           int first, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Patch embedding front end (PatchEmbed.forward, building_blocks.py:78-92): non-overlapping p×p(×p) patches of an
  * NCHW / NCHWD fp32 image are laid out as GEMM rows [B·L][C·p^nd] with K-order (c, ph, pw[, pd]) = the flattening of

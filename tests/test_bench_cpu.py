@@ -79,3 +79,41 @@ def test_committed_pmc_profiles_of_this_round_carry_a_source_hash():
     for f in glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]*pmc_traffic*.json")):
         d = json.load(open(f))
         assert len(d.get("src_hash", "")) == 16 and "families" in d, f
+
+
+def test_wgrad_queue_flushes_the_last_group_in_pairs_under_data_parallel(monkeypatch):
+    """the weight-gradient queue groups four Blocks per launch (768 tiles = 3 whole rounds of 256 CUs); with a data-parallel listener the
+    last four Blocks of a backward pass go out two by two, so the final all-reduce that nothing can overlap carries two Blocks' gradients
+    instead of four.  Policy only: the launches are faked."""
+    import torch
+    from UCF_VIT._hip import functional as HF
+    launches = []
+    monkeypatch.setattr(HF.ops, "wgrad_grouped", lambda items: launches.append(len(items)))
+    monkeypatch.setattr(HF.WgradQueue, "_arm", lambda self: None)       # (the autograd engine takes callbacks only inside a backward pass)
+
+    class Owner:
+        def poke(self):
+            pass
+    owner = Owner()
+
+    def one_pass(q, blocks):
+        for _ in range(blocks):
+            q.items += [(None, None, None, False)] * 4          # the four Linear layers of a Block
+            q.owners += [None] * 4
+            q.tiles += 192
+            q.end_block()
+        q._end_of_backward()
+
+    q = HF.WgradQueue()
+    one_pass(q, 24)
+    assert launches == [16] * 6                                   # single GPU: six launches of four Blocks
+    launches.clear()
+    import weakref
+    q.listeners.append(weakref.WeakMethod(owner.poke))
+    one_pass(q, 24)                                               # Block count known from the first pass
+    assert launches == [16] * 5 + [8, 8]
+    launches.clear()
+    q2 = HF.WgradQueue()
+    q2.listeners.append(weakref.WeakMethod(owner.poke))
+    one_pass(q2, 24)
+    assert launches == [16] * 6                                   # first pass of a fresh queue: the count is not known yet

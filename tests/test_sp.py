@@ -75,3 +75,139 @@ def test_seq_parallel_block_equals_unsharded(dtype_name, tol):
         assert p.exitcode == 0
     for rank, bad in res:
         assert not bad, f"SP rank {rank}: mismatch in {bad}"
+
+
+# ---------------------------------------------------------------------------------------------- cross-block attention + merge (one process)
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 1e-4), ("bfloat16", 2e-2)])
+@pytest.mark.parametrize("B,Nq,Nk_blocks,H,dh", [(2, 96, (64, 100), 3, 64), (1, 300, (256, 128, 77), 2, 32), (1, 130, (130,), 1, 128)])
+def test_cross_block_attention_and_merge(dtype_name, tol, B, Nq, Nk_blocks, H, dh):
+    """the ring building blocks: attention of Nq queries against key blocks held in OTHER buffers, folded by the log-sum-exp merge,
+    equals softmax(QK^T / sqrt(dh)) V over the concatenated keys; the per-block backward, given the FULL log-sum-exp and output,
+    accumulates exactly the full gradients (fp32 accumulators)."""
+    from UCF_VIT._hip import ops
+    dtype = getattr(torch, dtype_name)
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(Nq * 7 + dh)
+    W = H * dh
+    qbuf = torch.randn(B * Nq, W + 64, generator=gen).to(dtype).to(dev)           # padded rows: the kernels take leading dimensions
+    q = qbuf[:, :W]
+    blocks = [torch.randn(B * nk, 2 * W, generator=gen).to(dtype).to(dev) for nk in Nk_blocks]
+    do = torch.randn(B * Nq, W, generator=gen).to(dtype).to(dev)
+    o_acc = torch.empty(B * Nq, W, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+    for i, (kv, nk) in enumerate(zip(blocks, Nk_blocks)):
+        o_i, lse_i = ops.attention_cross_fwd(q, kv[:, :W], kv[:, W:], B, Nq, nk, H, dh, dh ** -0.5)
+        ops.attention_merge(o_acc, lse, o_i, lse_i, B, Nq, H, dh, first=(i == 0))
+    out = o_acc.to(dtype)
+    # fp32 reference over the concatenated keys
+    qf = q.float().view(B, Nq, H, dh).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    kf = [b_[:, :W].float().view(B, nk, H, dh).permute(0, 2, 1, 3).clone().requires_grad_(True) for b_, nk in zip(blocks, Nk_blocks)]
+    vf = [b_[:, W:].float().view(B, nk, H, dh).permute(0, 2, 1, 3).clone().requires_grad_(True) for b_, nk in zip(blocks, Nk_blocks)]
+    s = (qf @ torch.cat(kf, dim=2).transpose(-1, -2)) * dh ** -0.5
+    ref = (torch.softmax(s, dim=-1) @ torch.cat(vf, dim=2)).permute(0, 2, 1, 3).reshape(B * Nq, W)
+    ref.backward(do.float())
+    assert rel_err(out.float(), ref.detach()) < tol
+    ref_lse = torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634
+    assert float((lse - ref_lse).abs().max()) < (1e-3 if dtype == torch.float32 else 2e-2)
+    dq = torch.empty(B * Nq, W, dtype=torch.float32, device=dev)
+    for i, (kv, nk) in enumerate(zip(blocks, Nk_blocks)):
+        dk = torch.full((B * nk, W), 0.5, dtype=torch.float32, device=dev)           # accumulate = True adds to what is there
+        dv = torch.full((B * nk, W), -0.25, dtype=torch.float32, device=dev)
+        ops.attention_cross_bwd(q, kv[:, :W], kv[:, W:], out, do, lse, dq, dk, dv, B, Nq, nk, H, dh, dh ** -0.5, accumulate=(i > 0))
+        if i == 0:            # the first call overwrote
+            pass
+        else:
+            dk -= 0.5
+            dv += 0.25
+        gk = kf[i].grad.permute(0, 2, 1, 3).reshape(B * nk, W)
+        gv = vf[i].grad.permute(0, 2, 1, 3).reshape(B * nk, W)
+        assert rel_err(dk, gk) < tol, f"dk block {i}"
+        assert rel_err(dv, gv) < tol, f"dv block {i}"
+    assert rel_err(dq, qf.grad.permute(0, 2, 1, 3).reshape(B * Nq, W)) < tol
+
+
+# ---------------------------------------------------------------------------------------------- UNETR encoder, 2-D sequence parallelism
+def _unetr_sp_worker(rank, world, port, dtype_name, tol, ulysses, q):
+    for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from UCF_VIT.fsdp.arch import UNETR
+        from UCF_VIT.fsdp.seq_parallel import make_seq_parallel_groups, gather_tokens
+        from UCF_VIT.simple.arch import UNETR as UNETR1
+        from det_weights import det_state_dict, det_tensor
+        dtype = getattr(torch, dtype_name)
+        img = [128, 128, 128]                                    # p 16 -> 8 x 8 x 8 = 512 tokens; 12 heads like the 512x512x128 config
+        kw = dict(img_size=img, patch_size=16, in_chans=1, embed_dim=384, depth=4, num_heads=12, class_token=False, twoD=False, num_classes=4,
+                  linear_decoder=False, feature_size=4, skip_connection=True)
+        base = UNETR1(**kw)
+        sd = det_state_dict(base, 71)
+        base.load_state_dict(sd)
+        base = base.to("cuda:0")
+        base.set_compute_dtype(dtype)
+        x = det_tensor((1, 1, *img), 72).to("cuda:0")
+        gy = [det_tensor((1, 512, 384), 73 + i).to("cuda:0") for i in range(4)]
+        feats_r, taps_r = base.forward_intermediates(x, None, None, indices=base.skip_indices)
+        (sum((a.float() * g_).sum() for a, g_ in zip([feats_r] + taps_r, gy)) / world).backward()
+        spg = make_seq_parallel_groups([list(range(world))], 12, ulysses_size=ulysses)
+        m = UNETR(seq_par_size=world, seq_par_group=spg, **kw)
+        m.load_state_dict(sd)
+        m = m.to("cuda:0")
+        m.set_compute_dtype(dtype)
+        feats, taps = m.forward_intermediates(x, None, None, indices=m.skip_indices)
+        n = 512 // world
+        sl = slice(rank * n, (rank + 1) * n)
+        sum((a.float() * g_[:, sl]).sum() for a, g_ in zip([feats] + taps, gy)).backward()
+        bad = []
+        full = [gather_tokens(t.detach(), spg) for t in [feats] + taps]
+        for name, a, b in zip(["feats", "tap0", "tap1", "tap2"], full, [feats_r] + taps_r):
+            if tuple(a.shape) != (1, 512, 384) or rel_err(a.float(), b.detach().float()) >= tol:
+                bad.append(name)
+        enc = ("blocks.", "patch_embed.", "norm.", "pos_embed")
+        for (k, p), (_, pr) in zip(m.named_parameters(), base.named_parameters()):
+            if not k.startswith(enc):
+                continue
+            g = p.grad.detach().float().cpu()
+            dist.all_reduce(g)                                   # sum over the token shards ...
+            g /= world                                           # ... the mean over ranks = gradient of the mean objective
+            if rel_err(g, pr.grad.detach().float().cpu()) >= tol:
+                bad.append(k)
+        q.put((rank, bad, (spg.pu, spg.pr)))
+        dist.barrier()
+    except Exception as e:      # the parent must not sit out its queue timeout on a GPU box
+        import traceback
+        q.put((rank, ["EXCEPTION " + repr(e) + " " + traceback.format_exc()[-1500:]], (-1, -1)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,ulysses,dtype_name,tol", [(2, 1, "float32", 1e-3), (4, 2, "float32", 1e-3), (4, 2, "bfloat16", 6e-2)])
+def test_unetr_encoder_sequence_parallel_equals_unsharded(world, ulysses, dtype_name, tol):
+    """UNETR encoder (3-D patch embedding, 12 heads, taps) at N = 512 tokens sharded over `world` ranks that share the one GPU (gloo,
+    host-staged transport): pure ring (P_u = 1) and the 2-D grid P_u = 2 x P_r = 2 — the layout class of 12 heads on 8 GPUs (4 x 2) —
+    reproduce the unsharded features, taps and parameter gradients (pure Ulysses: test_seq_parallel_block_equals_unsharded; all five
+    combinations incl. P_u = 4 passed on the box when this test was written)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29570 + world * 3 + ulysses + (0 if dtype_name == "float32" else 40)
+    procs = [ctx.Process(target=_unetr_sp_worker, args=(r, world, port, dtype_name, tol, ulysses, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(world):
+        res.append(q.get(timeout=300))
+        if res[-1][2] == (-1, -1):                  # a rank raised: do not wait for the others (they hang in a collective)
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"SP rank {res[-1][0]}: {res[-1][1]}")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, grid in res:
+        assert grid == (ulysses, world // ulysses)
+        assert not bad, f"SP rank {rank}: mismatch in {bad}"

@@ -63,6 +63,10 @@ class WgradQueue:
         # publish_stream_colsum below): (dx tensor, fp32 [D] column sums)
         self.stream_colsum = None
         self.stream_colsum_armed = False
+        # Blocks per backward pass (learnt from the first pass): with a data-parallel listener the LAST group of four Blocks is flushed in
+        # pairs, so that only two Blocks' gradients (ViT-L: 50 MB of bf16) are still to be all-reduced when backward ends, not four
+        self.blocks_seen = 0
+        self.blocks_per_pass = 0
         _QUEUES.add(self)
 
     def add(self, weight, dy2, x2):
@@ -82,18 +86,27 @@ class WgradQueue:
 
     def end_block(self):
         """called when a Block's backward has queued its gradients"""
+        self.blocks_seen += 1
+        if not self.callback_armed:             # one callback per backward pass: flushes the rest and closes the Block count
+            self.callback_armed = True
+            self._arm()
         if not self.items:
             return
         rounds = -(-self.tiles // self.CUS)
         full = self.tiles >= 0.95 * rounds * self.CUS
-        if not (_DEFER_WGRAD and self.deferrable) or full or len(self.items) + 4 > self.MAX_PROBLEMS:
+        left = self.blocks_per_pass - self.blocks_seen           # Blocks of this pass still to come (unknown in the first pass: < 0)
+        tail = bool(self.listeners) and self.blocks_per_pass > 0 and 0 <= left < 4 and left % 2 == 0
+        if not (_DEFER_WGRAD and self.deferrable) or full or tail or len(self.items) + 4 > self.MAX_PROBLEMS:
             self.flush()
-        elif not self.callback_armed:
-            self.callback_armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _arm(self):
+        torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def _end_of_backward(self):
         self.callback_armed = False
+        if self.blocks_seen:
+            self.blocks_per_pass = self.blocks_seen
+        self.blocks_seen = 0
         self.flush()
 
     def flush(self):

@@ -53,6 +53,9 @@ SIGNATURES = {
     "ucfvit_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _I, _P, _I, _P]),
     "ucfvit_attention_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
+    "ucfvit_attention_cross_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P]),
+    "ucfvit_attention_cross_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P]),
+    "ucfvit_attention_merge": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P]),
     "ucfvit_im2col": (c_int, [_P, _P, _I64, _I64, POINTER(c_int64), _I, _I64, _I, _P]),
     "ucfvit_tokens_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P]),
     "ucfvit_tokens_bwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),

@@ -271,6 +271,39 @@ def attention_bwd(qkv, out, dout, lse, B, N, H, dh, scale):
     return dqkv
 
 
+def attention_cross_fwd(q, k, v, B, Nq, Nk, H, dh, scale):
+    """q [B*Nq, ldq], k / v [B*Nk, ldkv] (2-D views, head h at columns h*dh..) -> (out [B*Nq, H*dh], lse [B, H, Nq] in log2 units)"""
+    L = _l.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, "attention_cross_fwd." + n, rows_ok=True)
+    if k.stride(0) != v.stride(0) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("attention_cross_fwd: k and v must share their row stride, and all operands their dtype")
+    out = torch.empty((B * Nq, H * dh), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    _l.check(L.ucfvit_attention_cross_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, Nq, Nk, H, dh, q.stride(0),
+                                          k.stride(0), scale, dt(q), _stream()), "ucfvit_attention_cross_fwd")
+    return out, lse
+
+
+def attention_cross_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Nq, Nk, H, dh, scale, accumulate):
+    """this (query block, key block) pair's gradient terms, (+)= into fp32 dq [B*Nq, H*dh], dk / dv [B*Nk, H*dh]; lse / out: of the FULL softmax"""
+    L = _l.load()
+    _chk(dout, "attention_cross_bwd.dout"), _chk(out, "attention_cross_bwd.out")
+    for t in (dq, dk, dv):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("attention_cross_bwd: dq / dk / dv must be contiguous fp32")
+    delta = workspace(B * H * Nq * 4, q.device)
+    _l.check(L.ucfvit_attention_cross_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq.data_ptr(),
+                                          dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, Nq, Nk, H, dh, q.stride(0), k.stride(0), scale,
+                                          1 if accumulate else 0, dt(q), _stream()), "ucfvit_attention_cross_bwd")
+
+
+def attention_merge(o_acc, lse_acc, o_part, lse_part, B, Nq, H, dh, first):
+    L = _l.load()
+    _l.check(L.ucfvit_attention_merge(o_acc.data_ptr(), lse_acc.data_ptr(), o_part.data_ptr(), lse_part.data_ptr(), B, Nq, H, dh, 1 if first else 0,
+                                      dt(o_part), _stream()), "ucfvit_attention_merge")
+
+
 # ------------------------------------------------------------------------------------------------ front end
 def im2col(img, p, out_dtype):
     """img fp32 [B,C,H,W] or [B,C,H,W,Z] -> [B*L, C*p^nd] in out_dtype, K-order (c, ph, pw[, pd])"""

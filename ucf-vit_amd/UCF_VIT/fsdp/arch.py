@@ -90,3 +90,94 @@ class MAE(_TPMixin, _S.MAE):
         x = self.decoder_norm(self.decoder_blocks(x))
         x = self._tp_exit(x)
         return self.decoder_pred(x)
+
+
+class UNETR(_TPMixin, _S.UNETR):
+    """UNETR with the Hybrid-OP arguments of the reference's fsdp copy (src/UCF_VIT/fsdp/arch.py:1093-1130: tensor_par_size / _group, the
+    activation broadcast round the Blocks) plus SEQUENCE parallelism for the 8192-token volumes, under the names the reference already
+    plumbs but asserts off (seq_par_size / seq_par_group, utils/misc.py:147-160, train_masked_fsdp.py:220):
+
+        seq_par_group = UCF_VIT.fsdp.seq_parallel.make_seq_parallel_groups(...)   (a 2-D Ulysses x ring view of the group), or a plain
+                        process group (pure Ulysses, num_heads % seq_par_size == 0)
+
+    With seq_par_size > 1 every rank embeds and encodes its contiguous shard of the token sequence: forward_intermediates returns the
+    LOCAL shards [B, N / P, D] of the final features and of the taps (seq_parallel.gather_tokens reassembles them for the decoder)."""
+
+    def __init__(self, *args, **kwargs):
+        self.seq_par_size = kwargs.pop('seq_par_size', 1)
+        seq_par_group = kwargs.pop('seq_par_group', None)
+        kwargs = self._tp_setup(kwargs)
+        super().__init__(*args, **kwargs)
+        object.__setattr__(self, '_spg', None)
+        object.__setattr__(self, '_sp_blocks', None)
+        if self.seq_par_size > 1:
+            from .seq_parallel import SeqParallelBlock, SeqParallelGroups, _PlainGroup
+            assert self.tensor_par_size == 1, "tensor and sequence parallelism are not combined inside one Block"
+            assert not self.class_token and not self.adaptive_patching, "sequence parallelism shards a plain token grid (no class token)"
+            spg = seq_par_group if isinstance(seq_par_group, SeqParallelGroups) else _PlainGroup(seq_par_group)
+            assert spg.size == self.seq_par_size
+            object.__setattr__(self, '_spg', spg)
+            object.__setattr__(self, '_sp_blocks', [SeqParallelBlock(b, spg) for b in self.blocks])   # wrappers, not registered twice
+
+    def _embed_local_tokens(self, x):
+        """tokens [lo, hi) of the (h, w[, d]) row-major grid: whole slabs along the first spatial axis when the grid allows it (every rank
+        then reads 1 / P of the volume), else the full embedding sliced"""
+        spg, p = self._spg, self.patch_size
+        n = self.num_patches // spg.size
+        lo = spg.rank * n
+        g0 = self.grid_size[0]
+        rows = self.num_patches // g0                       # tokens per slab of one patch thickness
+        from UCF_VIT._hip import functional as HF
+        from UCF_VIT.simple.building_blocks import _cd
+        if n % rows == 0:
+            s0, s1 = (lo // rows) * p, ((lo + n) // rows) * p
+            pe = self.token_embeds                              # the slab through the same im2col + GEMM as PatchEmbed.forward
+            tok = HF.PatchEmbedFn.apply(x[:, :, s0:s1].contiguous(), pe.proj.weight, pe.proj.bias, p, _cd(self))
+        else:
+            tok = self.token_embeds(x)[:, lo:lo + n]
+        pos = self.pos_embed[:, lo:lo + n] if self.pos_embed is not None else None
+        return HF.TokensFn.apply(tok.contiguous(), None, pos, _cd(self)) if pos is not None else tok
+
+    def forward_intermediates(self, x, variables, seq_ps, indices=None, return_prefix_tokens=False, norm=False, stop_early=False,
+                              intermediates_only=False):
+        if self.seq_par_size <= 1:
+            if self.tensor_par_size <= 1:
+                return super().forward_intermediates(x, variables, seq_ps, indices, return_prefix_tokens, norm, stop_early, intermediates_only)
+            take, max_index = feature_take_indices(len(self.blocks), indices)
+            self._prepare()
+            x = self._tp_enter(self.patch_drop(self._pos_embed(self._embed_tokens(x, variables), seq_ps)))
+            intermediates = []
+            for i, blk in enumerate(self.blocks if not stop_early else self.blocks[:max_index + 1]):
+                x = blk(x)
+                if i in take:
+                    intermediates.append(self._tp_exit(self.norm(x) if norm else x))
+            if self.num_prefix_tokens:
+                intermediates = [y[:, self.num_prefix_tokens:] for y in intermediates]
+            return intermediates if intermediates_only else (self._tp_exit(self.norm(x)), intermediates)
+        take, max_index = feature_take_indices(len(self.blocks), indices)
+        self._prepare()
+        x = self._embed_local_tokens(x)
+        intermediates = []
+        blocks = self._sp_blocks if not stop_early else self._sp_blocks[:max_index + 1]
+        for i, blk in enumerate(blocks):
+            x = blk(x)
+            if i in take:
+                intermediates.append(self.norm(x) if norm else x)
+        return intermediates if intermediates_only else (self.norm(x), intermediates)
+
+
+class SAP(_TPMixin, _S.SAP):
+    """SAP with the Hybrid-OP arguments (reference fsdp/arch.py:1311-1338: tensor-parallel Blocks inside the broadcast bracket)"""
+
+    def __init__(self, *args, **kwargs):
+        kwargs = self._tp_setup(kwargs)
+        super().__init__(*args, **kwargs)
+
+    def forward_features(self, x, variables, seq_ps):
+        self._prepare()
+        x = self._embed_tokens(x, variables)
+        x = self._pos_embed(x, seq_ps)
+        x = self.patch_drop(x)
+        x = self._tp_enter(x)
+        x = self.norm(self.blocks(x))
+        return self._tp_exit(x)

@@ -12,6 +12,9 @@
 // the lane for dK/dV and the query on the lane for dQ, recomputing P from the saved log-sum-exp; no atomics, so
 // gradients are bitwise reproducible.
 #include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -175,6 +178,26 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Operands of the streaming kernels: every matrix is [batch][token][head][DH] with its own token / batch stride (in elements), so the same
+// kernels serve self-attention on the packed qkv GEMM output (q = qkv, k = qkv + D, v = qkv + 2D, token stride 3D) and attention of a
+// query block against ANOTHER token block's keys / values (ring sequence parallelism: UCF_VIT/fsdp/seq_parallel.py): Nq queries, Nk keys.
+template <typename T> struct AttnArgs {
+    const T* q;
+    const T* k;
+    const T* v;
+    const T* dout;        // backward
+    T* out;               // forward
+    void* dq;             // backward outputs: T, or float when the kernel is instantiated with OUTF (+= when accumulate)
+    void* dk;
+    void* dv;
+    float* lse;           // [B][H][Nq], log2 units (written by forward, read by backward)
+    const float* delta;   // [B][H][Nq] rowsum(dO * O) (backward)
+    int64_t sq, skv, so, sdo, sdq, sdkv;      // token strides
+    int64_t bq, bkv, bo, bdo, bdq, bdkv;      // batch strides
+    int Nq, Nk, H;
+    int accumulate;
+};
+
 // ===================================================================================================
 // Streaming kernels.  Template parameters shared by all three:
 //   QB   = 16-row blocks of the lane-resident index per wave (queries for forward / dQ, keys for dK/dV).  Every K / V (Q / dO) fragment
@@ -226,8 +249,7 @@ template <typename T, int DH, int NBUF> struct Stream {
 // forward
 // ===================================================================================================
 template <typename T, int DH, int QB, int NBUF>
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
-                                                               int N, int H, float scale_log2e) {
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const AttnArgs<T> a, float scale_log2e) {
     typedef AT<T, DH> A;
     typedef typename A::frag_t frag_t;
     typedef Stream<T, DH, NBUF> ST;
@@ -235,18 +257,20 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
-    const int D = H * DH;
-    const int64_t rs = 3 * (int64_t)D;  // token stride inside qkv
-    const T* qbase = qkv + b * N * rs + h * DH;
-    const T* kbase = qbase + D;
-    const T* vbase = qbase + 2 * D;
+    const int N = a.Nk, Nq = a.Nq, H = a.H;       // N: keys streamed; Nq: queries resident on the lanes
+    const int64_t rs = a.skv;
+    const T* qbase = a.q + b * a.bq + h * DH;
+    const T* kbase = a.k + b * a.bkv + h * DH;
+    const T* vbase = a.v + b * a.bkv + h * DH;
+    T* __restrict__ out = a.out;
+    float* __restrict__ lse = a.lse;
     const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB) + li;     // query of block qb: q0 + 16 qb
 
     frag_t qf[QB][A::NCH];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int c = 0; c < A::NCH; ++c) qf[qb][c] = frag_global<T, DH>(qbase, rs, q0 + 16 * qb, N, c, lane);
+        for (int c = 0; c < A::NCH; ++c) qf[qb][c] = frag_global<T, DH>(qbase, a.sq, q0 + 16 * qb, Nq, c, lane);
 
     f32x4 o[QB][A::NDB];
     // the row sums of P ride on the matrix pipe: an all-ones A fragment times Pᵀ gives, in EVERY accumulator row, the sum over the tile's
@@ -343,9 +367,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     for (int qb = 0; qb < QB; ++qb) {
         const float lt = lacc[qb][0];          // every accumulator row holds the full row sum of its query column
         const int q = q0 + 16 * qb;
-        if (q < N) {
+        if (q < Nq) {
             const float inv = 1.f / lt;
-            T* op = out + (b * N + q) * D + h * DH;
+            T* op = out + b * a.bo + q * a.so + h * DH;
 #pragma unroll
             for (int d = 0; d < A::NDB; ++d) {
                 Vec4<T> v;
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
                 for (int r = 0; r < 4; ++r) v.set(r, o[qb][d][r] * inv);
                 *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
             }
-            if (g == 0) lse[(b * H + h) * N + q] = m[qb] + log2f(lt);
+            if (g == 0) lse[(b * H + h) * (int64_t)Nq + q] = m[qb] + log2f(lt);
         }
     }
 }
@@ -387,23 +411,24 @@ __global__ void attn_delta_kernel(const T* __restrict__ out, const T* __restrict
 // ===================================================================================================
 // backward, dQ: query on the lane, loop over key tiles
 // ===================================================================================================
-template <typename T, int DH, int QB, int NBUF>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                  T* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
+template <typename T, int DH, int QB, int NBUF, bool OUTF>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const AttnArgs<T> a, float scale, float scale_log2e) {
     typedef AT<T, DH> A;
     typedef typename A::frag_t frag_t;
     typedef Stream<T, DH, NBUF> ST;
+    typedef typename std::conditional<OUTF, float, T>::type OT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
-    const int D = H * DH;
-    const int64_t rs = 3 * (int64_t)D;
-    const T* qbase = qkv + b * N * rs + h * DH;
-    const T* kbase = qbase + D;
-    const T* vbase = qbase + 2 * D;
-    const T* dobase = dout + b * N * (int64_t)D + h * DH;
+    const int N = a.Nk, Nq = a.Nq, H = a.H;
+    const int64_t rs = a.skv;
+    const T* qbase = a.q + b * a.bq + h * DH;
+    const T* kbase = a.k + b * a.bkv + h * DH;
+    const T* vbase = a.v + b * a.bkv + h * DH;
+    const T* dobase = a.dout + b * a.bdo + h * DH;
+    const float* __restrict__ lse = a.lse;
+    const float* __restrict__ delta = a.delta;
     const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB) + li;
 
     frag_t qf[QB][A::NCH], dof[QB][A::NCH];
@@ -414,11 +439,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
         const int q = q0 + 16 * qb;
 #pragma unroll
         for (int c = 0; c < A::NCH; ++c) {
-            qf[qb][c] = frag_global<T, DH>(qbase, rs, q, N, c, lane);
-            dof[qb][c] = frag_global<T, DH>(dobase, D, q, N, c, lane);
+            qf[qb][c] = frag_global<T, DH>(qbase, a.sq, q, Nq, c, lane);
+            dof[qb][c] = frag_global<T, DH>(dobase, a.sdo, q, Nq, c, lane);
         }
-        my_lse[qb] = q < N ? lse[(b * H + h) * N + q] : 0.f;
-        my_delta[qb] = q < N ? delta[(b * H + h) * N + q] : 0.f;
+        my_lse[qb] = q < Nq ? lse[(b * H + h) * (int64_t)Nq + q] : 0.f;
+        my_delta[qb] = q < Nq ? delta[(b * H + h) * (int64_t)Nq + q] : 0.f;
 #pragma unroll
         for (int d = 0; d < A::NDB; ++d) dq[qb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -480,14 +505,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int q = q0 + 16 * qb;
-        if (q < N) {
-            T* op = dqkv + (b * N + q) * rs + h * DH;
+        if (q < Nq) {
+            OT* op = reinterpret_cast<OT*>(a.dq) + b * a.bdq + q * a.sdq + h * DH;
 #pragma unroll
             for (int d = 0; d < A::NDB; ++d) {
-                Vec4<T> v;
+                Vec4<OT> v;
+                if (a.accumulate) v = *reinterpret_cast<const Vec4<OT>*>(op + d * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v.set(r, dq[qb][d][r] * scale);
-                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
+                for (int r = 0; r < 4; ++r) v.set(r, dq[qb][d][r] * scale + (a.accumulate ? v.get(r) : 0.f));
+                *reinterpret_cast<Vec4<OT>*>(op + d * 16 + 4 * g) = v;
             }
         }
     }
@@ -496,27 +522,27 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
 // ===================================================================================================
 // backward, dK / dV: key on the lane, loop over query tiles
 // ===================================================================================================
-template <typename T, int DH, int QB, int NBUF>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                   T* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
+template <typename T, int DH, int QB, int NBUF, bool OUTF>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const AttnArgs<T> a, float scale, float scale_log2e) {
     typedef AT<T, DH> A;
     typedef typename A::frag_t frag_t;
     typedef Stream<T, DH, NBUF> ST;
+    typedef typename std::conditional<OUTF, float, T>::type OT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per-query constants of the streamed tile, one [2][64] float pair per pipeline buffer, behind the tile buffers
     float* ldsRow = reinterpret_cast<float*>(smem + NBUF * ST::PAIR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
-    const int D = H * DH;
-    const int64_t rs = 3 * (int64_t)D;
-    const T* qbase = qkv + b * N * rs + h * DH;
-    const T* kbase = qbase + D;
-    const T* vbase = qbase + 2 * D;
-    const T* dobase = dout + b * N * (int64_t)D + h * DH;
-    const float* lse_bh = lse + (b * H + h) * N;
-    const float* delta_bh = delta + (b * H + h) * N;
+    const int N = a.Nq, Nk = a.Nk, H = a.H;        // N: queries streamed; Nk: keys resident on the lanes
+    const int64_t rs = a.sq;
+    const int64_t D = a.sdo;                       // token stride of dO
+    const T* qbase = a.q + b * a.bq + h * DH;
+    const T* kbase = a.k + b * a.bkv + h * DH;
+    const T* vbase = a.v + b * a.bkv + h * DH;
+    const T* dobase = a.dout + b * a.bdo + h * DH;
+    const float* lse_bh = a.lse + (b * H + h) * (int64_t)N;
+    const float* delta_bh = a.delta + (b * H + h) * (int64_t)N;
     const int key0 = blockIdx.x * (64 * QB) + wave * (16 * QB) + li;
 
     frag_t kf[QB][A::NCH], vf[QB][A::NCH];
@@ -525,8 +551,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
         for (int c = 0; c < A::NCH; ++c) {
-            kf[qb][c] = frag_global<T, DH>(kbase, rs, key0 + 16 * qb, N, c, lane);
-            vf[qb][c] = frag_global<T, DH>(vbase, rs, key0 + 16 * qb, N, c, lane);
+            kf[qb][c] = frag_global<T, DH>(kbase, a.skv, key0 + 16 * qb, Nk, c, lane);
+            vf[qb][c] = frag_global<T, DH>(vbase, a.skv, key0 + 16 * qb, Nk, c, lane);
         }
 #pragma unroll
         for (int d = 0; d < A::NDB; ++d) {
@@ -644,19 +670,23 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int key = key0 + 16 * qb;
-        if (key < N) {
-            T* kp = dqkv + (b * N + key) * rs + D + h * DH;
-            T* vp = kp + D;
+        if (key < Nk) {
+            OT* kp = reinterpret_cast<OT*>(a.dk) + b * a.bdkv + key * a.sdkv + h * DH;
+            OT* vp = reinterpret_cast<OT*>(a.dv) + b * a.bdkv + key * a.sdkv + h * DH;
 #pragma unroll
             for (int d = 0; d < A::NDB; ++d) {
-                Vec4<T> a, c;
+                Vec4<OT> ka, va;
+                if (a.accumulate) {
+                    ka = *reinterpret_cast<const Vec4<OT>*>(kp + d * 16 + 4 * g);
+                    va = *reinterpret_cast<const Vec4<OT>*>(vp + d * 16 + 4 * g);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a.set(r, dk[qb][d][r] * scale);
-                    c.set(r, dv[qb][d][r]);
+                    ka.set(r, dk[qb][d][r] * scale + (a.accumulate ? ka.get(r) : 0.f));
+                    va.set(r, dv[qb][d][r] + (a.accumulate ? va.get(r) : 0.f));
                 }
-                *reinterpret_cast<Vec4<T>*>(kp + d * 16 + 4 * g) = a;
-                *reinterpret_cast<Vec4<T>*>(vp + d * 16 + 4 * g) = c;
+                *reinterpret_cast<Vec4<OT>*>(kp + d * 16 + 4 * g) = ka;
+                *reinterpret_cast<Vec4<OT>*>(vp + d * 16 + 4 * g) = va;
             }
         }
     }
@@ -681,14 +711,62 @@ template <typename K> int allow_big_lds(K kernel, size_t bytes) {
 }
 
 template <typename T, int DH>
-int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+int attn_fwd_launch_args(const AttnArgs<T>& a, int64_t B, float scale, hipStream_t s) {
     typedef Geo<T, DH> G;
-    const dim3 grid((unsigned)((N + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)H, (unsigned)B);
+    const dim3 grid((unsigned)((a.Nq + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)a.H, (unsigned)B);
     auto kern = attn_fwd_kernel<T, DH, G::QB, G::NBUF>;
     if (int rc = allow_big_lds(kern, G::SMEM)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(AT_THREADS), G::SMEM, s, (const T*)qkv, (T*)out, lse, (int)N, (int)H, scale * 1.44269504088896340736f);
+    hipLaunchKernelGGL(kern, grid, dim3(AT_THREADS), G::SMEM, s, a, scale * 1.44269504088896340736f);
     UCF_LAUNCH_CHECK("ucfvit_attention_fwd");
     return UCFVIT_OK;
+}
+
+// delta + dQ + dK/dV launches; `out` / `a.dout` are contiguous [B][Nq][H][DH]
+template <typename T, int DH, bool OUTF>
+int attn_bwd_launch_args(AttnArgs<T> a, const void* out, float* delta, int64_t B, float scale, hipStream_t s) {
+    typedef Geo<T, DH> G;
+    const int64_t nd = B * a.Nq * a.H * (DH / (16 / (int64_t)sizeof(T)));
+    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, a.dout, delta, B, a.Nq,
+                       a.H);
+    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");
+    a.delta = delta;
+    const float sl2 = scale * 1.44269504088896340736f;
+    auto k_dq = attn_bwd_dq_kernel<T, DH, G::QB, G::NBUF, OUTF>;
+    auto k_dkv = attn_bwd_dkv_kernel<T, DH, G::QB, G::NBUF, OUTF>;
+    if (int rc = allow_big_lds(k_dq, G::SMEM)) return rc;
+    if (int rc = allow_big_lds(k_dkv, G::SMEM_DKV)) return rc;
+    const dim3 grid_q((unsigned)((a.Nq + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)a.H, (unsigned)B);
+    const dim3 grid_k((unsigned)((a.Nk + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)a.H, (unsigned)B);
+    hipLaunchKernelGGL(k_dq, grid_q, dim3(AT_THREADS), G::SMEM, s, a, scale, sl2);
+    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(dq)");
+    hipLaunchKernelGGL(k_dkv, grid_k, dim3(AT_THREADS), G::SMEM_DKV, s, a, scale, sl2);
+    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(dkv)");
+    return UCFVIT_OK;
+}
+
+// self-attention on the packed qkv GEMM output [B][N][3][H][DH]
+template <typename T> AttnArgs<T> self_args(const void* qkv, int64_t N, int64_t H, int64_t DH) {
+    AttnArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    const int64_t D = H * DH;
+    a.q = (const T*)qkv;
+    a.k = a.q + D;
+    a.v = a.q + 2 * D;
+    a.sq = a.skv = 3 * D;
+    a.bq = a.bkv = N * 3 * D;
+    a.so = a.sdo = D;
+    a.bo = a.bdo = N * D;
+    a.Nq = a.Nk = (int)N;
+    a.H = (int)H;
+    return a;
+}
+
+template <typename T, int DH>
+int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+    AttnArgs<T> a = self_args<T>(qkv, N, H, DH);
+    a.out = (T*)out;
+    a.lse = lse;
+    return attn_fwd_launch_args<T, DH>(a, B, scale, s);
 }
 
 template <typename T, int DH>
@@ -701,23 +779,113 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;
     }
-    typedef Geo<T, DH> G;
-    const int64_t nd = B * N * H * (DH / (16 / (int64_t)sizeof(T)));
-    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, B,
-                       (int)N, (int)H);
-    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(delta)");
-    const dim3 grid((unsigned)((N + 64 * G::QB - 1) / (64 * G::QB)), (unsigned)H, (unsigned)B);
-    const float sl2 = scale * 1.44269504088896340736f;
-    auto k_dq = attn_bwd_dq_kernel<T, DH, G::QB, G::NBUF>;
-    auto k_dkv = attn_bwd_dkv_kernel<T, DH, G::QB, G::NBUF>;
-    if (int rc = allow_big_lds(k_dq, G::SMEM)) return rc;
-    if (int rc = allow_big_lds(k_dkv, G::SMEM_DKV)) return rc;
-    hipLaunchKernelGGL(k_dq, grid, dim3(AT_THREADS), G::SMEM, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta, (T*)dqkv, (int)N,
-                       (int)H, scale, sl2);
-    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(dq)");
-    hipLaunchKernelGGL(k_dkv, grid, dim3(AT_THREADS), G::SMEM_DKV, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta, (T*)dqkv,
-                       (int)N, (int)H, scale, sl2);
-    UCF_LAUNCH_CHECK("ucfvit_attention_bwd(dkv)");
+    AttnArgs<T> a = self_args<T>(qkv, N, H, DH);
+    const int64_t D = H * DH;
+    a.dout = (const T*)dout;
+    a.lse = const_cast<float*>(lse);
+    a.dq = dqkv;
+    a.dk = (T*)dqkv + D;
+    a.dv = (T*)dqkv + 2 * D;
+    a.sdq = a.sdkv = 3 * D;
+    a.bdq = a.bdkv = N * 3 * D;
+    return attn_bwd_launch_args<T, DH, false>(a, out, delta, B, scale, s);
+}
+
+// ---- attention of a query block against another block's keys / values (ring sequence parallelism) ------------------------------------
+template <typename T, int DH>
+int attn_cross_fwd_launch(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t Nq, int64_t Nk, int64_t H,
+                          int64_t ldq, int64_t ldkv, float scale, hipStream_t s) {
+    AttnArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const T*)q;
+    a.k = (const T*)k;
+    a.v = (const T*)v;
+    a.out = (T*)out;
+    a.lse = lse;
+    a.sq = ldq;
+    a.skv = ldkv;
+    a.bq = Nq * ldq;
+    a.bkv = Nk * ldkv;
+    a.so = H * DH;
+    a.bo = Nq * H * DH;
+    a.Nq = (int)Nq;
+    a.Nk = (int)Nk;
+    a.H = (int)H;
+    return attn_fwd_launch_args<T, DH>(a, B, scale, s);
+}
+
+template <typename T, int DH>
+int attn_cross_bwd_launch(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse, float* dq, float* dk,
+                          float* dv, float* delta, int64_t B, int64_t Nq, int64_t Nk, int64_t H, int64_t ldq, int64_t ldkv, float scale,
+                          int accumulate, hipStream_t s) {
+    AttnArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    const int64_t D = H * DH;
+    a.q = (const T*)q;
+    a.k = (const T*)k;
+    a.v = (const T*)v;
+    a.dout = (const T*)dout;
+    a.lse = const_cast<float*>(lse);
+    a.dq = dq;
+    a.dk = dk;
+    a.dv = dv;
+    a.sq = ldq;
+    a.skv = ldkv;
+    a.bq = Nq * ldq;
+    a.bkv = Nk * ldkv;
+    a.so = a.sdo = a.sdq = a.sdkv = D;
+    a.bo = a.bdo = a.bdq = Nq * D;
+    a.bdkv = Nk * D;
+    a.Nq = (int)Nq;
+    a.Nk = (int)Nk;
+    a.H = (int)H;
+    a.accumulate = accumulate;
+    return attn_bwd_launch_args<T, DH, true>(a, out, delta, B, scale, s);
+}
+
+// online merge of two partial attention results over disjoint key sets (log2-domain log-sum-exp):
+//   lse' = log2(2^lse_acc + 2^lse_part),  o' = o_acc 2^(lse_acc - lse') + o_part 2^(lse_part - lse');  first: plain copy
+template <typename T, int DH>
+__global__ void attn_merge_kernel(float* __restrict__ o_acc, float* __restrict__ lse_acc, const T* __restrict__ o_part,
+                                  const float* __restrict__ lse_part, int64_t B, int Nq, int H, int first) {
+    constexpr int V = DH / 4;                                   // 4-element pieces per (token, head)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (b, q, h, piece)
+    if (i >= B * Nq * H * V) return;
+    const int piece = (int)(i % V);
+    const int64_t bqh = i / V;
+    const int h = (int)(bqh % H);
+    const int64_t bq = bqh / H;
+    const int q = (int)(bq % Nq);
+    const int64_t b = bq / Nq;
+    const int64_t li = (b * H + h) * (int64_t)Nq + q;
+    const float lp = lse_part[li];
+    const Vec4<T> p = *reinterpret_cast<const Vec4<T>*>(o_part + i * 4);
+    f32x4 r;
+    float ln = lp;
+    if (first) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = p.get(e);
+    } else {
+        const float la = lse_acc[li];
+        const float mx = fmaxf(la, lp);
+        ln = mx + log2f(__builtin_amdgcn_exp2f(la - mx) + __builtin_amdgcn_exp2f(lp - mx));
+        const float wa = __builtin_amdgcn_exp2f(la - ln), wp = __builtin_amdgcn_exp2f(lp - ln);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(o_acc + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = o[e] * wa + p.get(e) * wp;
+    }
+    *reinterpret_cast<f32x4*>(o_acc + i * 4) = r;
+    __syncthreads();      // every piece of a (token, head) sits in one workgroup (V divides 256): all have read lse_acc before it changes
+    if (piece == 0) lse_acc[li] = ln;
+}
+
+template <typename T, int DH>
+int attn_merge_launch(float* o_acc, float* lse_acc, const void* o_part, const float* lse_part, int64_t B, int64_t Nq, int64_t H, int first,
+                      hipStream_t s) {
+    const int64_t n = B * Nq * H * (DH / 4);
+    hipLaunchKernelGGL((attn_merge_kernel<T, DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o_acc, lse_acc, (const T*)o_part, lse_part, B,
+                       (int)Nq, (int)H, first);
+    UCF_LAUNCH_CHECK("ucfvit_attention_merge");
     return UCFVIT_OK;
 }
 
@@ -767,4 +935,43 @@ extern "C" int ucfvit_attention_bwd(const void* qkv, const void* out, const void
     UCF_CHECK_ARG(ucf_is_aligned16(qkv) && ucf_is_aligned16(out) && ucf_is_aligned16(dout) && ucf_is_aligned16(dqkv),
                   "ucfvit_attention_bwd: pointers must be 16-byte aligned");
     ATTN_DISPATCH(attn_bwd_launch, qkv, out, dout, lse, dqkv, delta_ws, B, N, H, scale, (hipStream_t)stream);
+}
+
+extern "C" int ucfvit_attention_cross_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t Nq, int64_t Nk,
+                                          int64_t H, int64_t dh, int64_t ldq, int64_t ldkv, float scale, int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;
+    UCF_CHECK_ARG(q && k && v && out && lse, "ucfvit_attention_cross_fwd: null pointer");
+    int rc = check_attn_args("ucfvit_attention_cross_fwd", B, Nq, H, dh, dtype);
+    if (rc) return rc;
+    UCF_CHECK_ARG(Nk > 0 && Nk < (1ll << 30) && ldq >= H * dh && ldkv >= H * dh && ldq % 8 == 0 && ldkv % 8 == 0,
+                  "ucfvit_attention_cross_fwd: need Nk > 0 and row strides >= H*dh, multiples of 8 elements");
+    UCF_CHECK_ARG(ucf_is_aligned16(q) && ucf_is_aligned16(k) && ucf_is_aligned16(v) && ucf_is_aligned16(out),
+                  "ucfvit_attention_cross_fwd: pointers must be 16-byte aligned");
+    ATTN_DISPATCH(attn_cross_fwd_launch, q, k, v, out, lse, B, Nq, Nk, H, ldq, ldkv, scale, (hipStream_t)stream);
+}
+
+extern "C" int ucfvit_attention_cross_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                                          float* dq, float* dk, float* dv, float* delta_ws, int64_t B, int64_t Nq, int64_t Nk, int64_t H,
+                                          int64_t dh, int64_t ldq, int64_t ldkv, float scale, int accumulate, int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;
+    UCF_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && delta_ws, "ucfvit_attention_cross_bwd: null pointer");
+    int rc = check_attn_args("ucfvit_attention_cross_bwd", B, Nq, H, dh, dtype);
+    if (rc) return rc;
+    UCF_CHECK_ARG(Nk > 0 && Nk < (1ll << 30) && ldq >= H * dh && ldkv >= H * dh && ldq % 8 == 0 && ldkv % 8 == 0,
+                  "ucfvit_attention_cross_bwd: need Nk > 0 and row strides >= H*dh, multiples of 8 elements");
+    UCF_CHECK_ARG(ucf_is_aligned16(q) && ucf_is_aligned16(k) && ucf_is_aligned16(v) && ucf_is_aligned16(out) && ucf_is_aligned16(dout) &&
+                      ucf_is_aligned16(dq) && ucf_is_aligned16(dk) && ucf_is_aligned16(dv),
+                  "ucfvit_attention_cross_bwd: pointers must be 16-byte aligned");
+    ATTN_DISPATCH(attn_cross_bwd_launch, q, k, v, out, dout, lse, dq, dk, dv, delta_ws, B, Nq, Nk, H, ldq, ldkv, scale, accumulate,
+                  (hipStream_t)stream);
+}
+
+extern "C" int ucfvit_attention_merge(float* o_acc, float* lse_acc, const void* o_part, const float* lse_part, int64_t B, int64_t Nq, int64_t H,
+                                      int64_t dh, int first, int dtype, void* stream) {
+    if (B == 0) return UCFVIT_OK;
+    UCF_CHECK_ARG(o_acc && lse_acc && o_part && lse_part, "ucfvit_attention_merge: null pointer");
+    int rc = check_attn_args("ucfvit_attention_merge", B, Nq, H, dh, dtype);
+    if (rc) return rc;
+    UCF_CHECK_ARG(ucf_is_aligned16(o_acc) && (((uintptr_t)o_part) & 7) == 0, "ucfvit_attention_merge: o_acc 16-byte, o_part 8-byte aligned");
+    ATTN_DISPATCH(attn_merge_launch, o_acc, lse_acc, o_part, lse_part, B, Nq, H, first, (hipStream_t)stream);
 }
