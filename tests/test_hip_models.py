@@ -792,3 +792,73 @@ def test_optimizer_loads_a_torch_adamw_state_dict():
     hopt.step()
     for n, p in named:
         assert rel_err(p.detach(), want[n]) < 1e-6, n
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY §8f row 4 remainder
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_activation_checkpointing_of_blocks_is_exact_and_saves_memory(dtype):
+    """apply_activation_checkpointing (the reference wraps every Block, train_masked_fsdp.py:393-396): the Blocks keep only their input and
+    re-run their forward launches in backward; logits, loss and EVERY gradient are bit-identical to the plain run, and the activations
+    held between forward and backward shrink."""
+    from UCF_VIT.simple.arch import VIT
+    from UCF_VIT.simple.building_blocks import apply_activation_checkpointing
+    from UCF_VIT.utils.metrics import cross_entropy_loss
+    kw = dict(img_size=[64, 64], patch_size=8, in_chans=3, num_classes=7, embed_dim=128, depth=6, num_heads=4)
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(16, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 7, (16,), generator=g).to(DEV)
+
+    def run(ckpt):
+        m = build(VIT, kw, 41, dtype)
+        if ckpt:
+            assert apply_activation_checkpointing(m) == 6
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        out = m(x, VARS)
+        loss = cross_entropy_loss(out, y)
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base
+        loss.backward()
+        return out.detach(), loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, held
+
+    o0, l0, g0, held0 = run(False)
+    o1, l1, g1, held1 = run(True)
+    assert torch.equal(o0, o1) and l0 == l1
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert held1 < 0.45 * held0, (held0, held1)
+
+
+def test_mae_encoder_transfers_into_unetr_and_tp_checkpoint_names(tmp_path):
+    """train_unetr_simple.py:328-340: the pretrained MAE's encoder entries (no 'decoder', no 'mask_token') overwrite the UNETR's, its conv
+    decoder keeps its initialisation; train_masked_fsdp.py:624-644: one checkpoint per tensor-parallel rank, `_even_rank_<r>.ckpt`"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ucf-vit_amd", "training_scripts"))
+    from UCF_VIT.simple.arch import MAE, UNETR
+    from UCF_VIT.utils.misc import configure_optimizer, configure_scheduler
+    from _common import load_pretrained_mae_encoder, save_checkpoint_tp
+    enc = dict(img_size=[32, 32, 16], patch_size=8, in_chans=1, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False)
+    mae = MAE(weight_init='skip', mask_ratio=0.75, linear_decoder=False, decoder_depth=1, decoder_embed_dim=48, decoder_num_heads=3,
+              mlp_ratio_decoder=4.0, **enc)
+    mae.load_state_dict(det_state_dict(mae, 91))
+    un = UNETR(num_classes=4, linear_decoder=False, feature_size=4, skip_connection=True, **enc)
+    before = {k: v.clone() for k, v in un.state_dict().items()}
+    sd = {"module." + k: v for k, v in mae.state_dict().items()}             # a DDP-saved checkpoint
+    copied = load_pretrained_mae_encoder(un, sd)
+    after = un.state_dict()
+    assert copied and all("decoder" not in k and "mask_token" not in k for k in copied)
+    for k in copied:
+        assert torch.equal(after[k], mae.state_dict()[k]), k
+    for k in after:
+        if k not in copied:
+            assert torch.equal(after[k], before[k]), k                       # conv decoder untouched
+    assert any(k.startswith("blocks.3.") for k in copied) and any(k.startswith("decoder5.") for k in after if k not in copied)
+    un = un.to(DEV)
+    opt = configure_optimizer(un, 1e-3, 0.9, 0.95, 0.0)
+    sch = configure_scheduler(opt, 2, 10, 1e-8, 1e-8)
+    conf = {"trainer": {"checkpoint_path": str(tmp_path), "checkpoint_filename": "hy"}}
+    for r in range(3):
+        save_checkpoint_tp(conf, 2, un, opt, sch, [0.5], world_rank=r, tensor_par_size=2)
+    assert sorted(os.listdir(tmp_path)) == ["hy_even_rank_0.ckpt", "hy_even_rank_1.ckpt"]
+    ck = torch.load(os.path.join(tmp_path, "hy_even_rank_1.ckpt"), map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "loss_list"} and ck["epoch"] == 2

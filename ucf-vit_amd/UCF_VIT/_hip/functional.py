@@ -463,27 +463,47 @@ class BlockFn(torch.autograd.Function):
     activation fused into GEMM epilogues; the residual-branch gradients are fused into the LayerNorm backward."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b, num_heads, eps, cdtype, tp=None):
-        xin = _as(x, cdtype)
-        B, N, D = xin.shape
-        x2 = xin.view(B * N, D)
-        c = lambda p: compute_param(p, cdtype)
+    def _run_forward(x2, B, N, num_heads, eps, c, params, tp):
+        n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b = params
         ln1, mean1, rstd1 = ops.layernorm_fwd(x2, c(n1w), c(n1b), eps)
         x1, sa = _attn_fwd(ln1, B, N, num_heads, c(qkvw), c(qkvb), c(projw), c(projb), x2, tp)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, c(n2w), c(n2b), eps)
         y, sm = _mlp_fwd(ln2, c(f1w), c(f1b), c(f2w), c(f2b), x1, tp)
-        ctx.save_for_backward(x2, mean1, rstd1, ln1, *sa, x1, mean2, rstd2, ln2, *sm,
-                              n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b)
+        return y, (mean1, rstd1, ln1, *sa, x1, mean2, rstd2, ln2, *sm)
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b, num_heads, eps, cdtype, tp=None, recompute=False):
+        """recompute = activation checkpointing of the Block (reference: apply_activation_checkpointing(Block),
+        training_scripts/train_masked_fsdp.py:393-396): only the Block's INPUT is kept; backward re-runs the seven forward launches to
+        rebuild ln1, qkv, o, lse, x1, ln2, h, a (15 of the 16 token matrices a Block otherwise keeps), then proceeds as usual.  The
+        rebuilt tensors are bit-identical (no atomics, fixed reduction orders), so gradients equal the non-checkpointed ones exactly."""
+        xin = _as(x, cdtype)
+        B, N, D = xin.shape
+        x2 = xin.view(B * N, D)
+        c = lambda p: compute_param(p, cdtype)
+        params = (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b)
+        y, saved = BlockFn._run_forward(x2, B, N, num_heads, eps, c, params, tp)
+        if recompute:
+            ctx.save_for_backward(x2, *params)
+        else:
+            ctx.save_for_backward(x2, *saved, *params)
         ctx.meta = (B, N, num_heads, cdtype, x.dtype, tp)
+        ctx.recompute, ctx.eps = recompute, eps
         return y.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dy):
-        (x2, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, h, a,
-         n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b) = ctx.saved_tensors
         B, N, H, cdtype, in_dtype, tp = ctx.meta
-        need = ctx.needs_input_grad
         c = lambda p: compute_param(p, cdtype)
+        if ctx.recompute:
+            x2, *params = ctx.saved_tensors
+            _, saved = BlockFn._run_forward(x2, B, N, H, ctx.eps, c, tuple(params), tp)
+            (mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, h, a) = saved
+            n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b = params
+        else:
+            (x2, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, h, a,
+             n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, f1w, f1b, f2w, f2b) = ctx.saved_tensors
+        need = ctx.needs_input_grad
         dy2 = _as(dy, cdtype).reshape(x2.shape)
         wq = _queue_for(qkvw)
         dln2, gm = _mlp_bwd(dy2, ln2, (h, a), c(f1w), c(f2w), f1w, f1b, f2w, f2b, need[9:13], tp, wq, dy2_colsum=_take_stream_colsum(wq, dy2))
@@ -505,7 +525,7 @@ class BlockFn(torch.autograd.Function):
         if cs0 is not None and in_dtype == cdtype:
             _publish_stream_colsum(wq, dx, cs0)
         wq.end_block()                                   # the Block's 4 weight gradients: grouped launch now, or with the next Blocks'
-        return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None)
+        return (_ret_grad(dx.view(B, N, -1), in_dtype), g_n1w, g_n1b) + ga + (g_n2w, g_n2b) + gm + (None, None, None, None, None)
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -110,6 +110,7 @@ class Block(nn.Module):
             _no_dropout(m.drop1.p, self.training, "Mlp.drop")
             return HF.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                     self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
-                                    a.num_heads, self.norm1.eps, _cd(self), _tp(self.tensor_par_size, self.tensor_par_group))
+                                    a.num_heads, self.norm1.eps, _cd(self), _tp(self.tensor_par_size, self.tensor_par_group),
+                                    getattr(self, "activation_checkpointing", False) and torch.is_grad_enabled())
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
         return x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))

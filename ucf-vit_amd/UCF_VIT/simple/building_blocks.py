@@ -229,6 +229,7 @@ class Block(nn.Module):
         self.mlp = mlp_layer(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=proj_drop)
         self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
         self.drop_path2 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.activation_checkpointing = False      # set by apply_activation_checkpointing(): keep only the Block's input for backward
 
     def _fusable(self):
         return (isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
@@ -249,7 +250,7 @@ class Block(nn.Module):
             _no_dropout(m.drop1.p, self.training, "Mlp.drop")
             return HF.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                     self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
-                                    a.num_heads, self.norm1.eps, _cd(self))
+                                    a.num_heads, self.norm1.eps, _cd(self), None, self.activation_checkpointing and torch.is_grad_enabled())
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
         x = x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
         return x
@@ -318,3 +319,15 @@ class VariableMapping_Attention(nn.Module):
         kv = self.kv(x.reshape(V * R, D))                         # [V * R, 2 D]
         out = HF.VarAggFn.apply(kv, q, V, self.head_dim, self.scale)
         return self.proj(out)
+
+
+def apply_activation_checkpointing(model, check_fn=None):
+    """the reference's `apply_activation_checkpointing(model, checkpoint_wrapper_fn=checkpoint_wrapper, check_fn=lambda m: isinstance(m, Block))`
+    (training_scripts/train_masked_fsdp.py:393-396) for the HIP Blocks: every Block (or every module check_fn accepts) keeps only its input
+    and re-runs its forward launches inside backward (HF.BlockFn recompute).  Returns the number of Blocks switched."""
+    n = 0
+    for mod in model.modules():
+        if isinstance(mod, Block) and (check_fn is None or check_fn(mod)):
+            mod.activation_checkpointing = True
+            n += 1
+    return n

@@ -150,6 +150,41 @@ def save_checkpoint(conf, epoch, model, optimizer, scheduler, loss_list, rank):
     dist.barrier()
 
 
+def save_checkpoint_tp(conf, epoch, model, optimizer, scheduler, loss_list, world_rank, tensor_par_size):
+    """Hybrid-OP checkpoints (reference train_masked_fsdp.py:624-644): ONE file per tensor-parallel rank of the first TP group,
+    `<name>_<even|odd>_rank_<r>.ckpt`, same dictionary keys as the simple scripts.  (The reference stores epoch_start + max_epochs under
+    'epoch'; this build stores the epoch that was just finished, which is what its own resume path reads back.)"""
+    t = conf["trainer"]
+    if world_rank < tensor_par_size:
+        os.makedirs(t["checkpoint_path"], exist_ok=True)
+        torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                    "scheduler_state_dict": scheduler.state_dict(), "loss_list": loss_list},
+                   os.path.join(t["checkpoint_path"], f"{t['checkpoint_filename']}_{'even' if epoch % 2 == 0 else 'odd'}_rank_{world_rank}.ckpt"))
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def load_pretrained_mae_encoder(model, mae_state_dict):
+    """MAE -> UNETR / SAP encoder transfer (reference train_unetr_simple.py:328-340): every entry of the pretrained MAE's state_dict whose
+    name contains neither 'decoder' nor 'mask_token' overwrites the same-named entry of `model`; everything else of `model` (conv decoder,
+    heads) keeps its initialisation.  `mae_state_dict` may carry the DDP 'module.' prefix on either side.  Returns the names copied."""
+    strip = lambda k: k[len("module."):] if k.startswith("module.") else k
+    enc = {strip(k): v for k, v in mae_state_dict.items() if "decoder" not in k and "mask_token" not in k}
+    own = model.state_dict()
+    prefixed = any(k.startswith("module.") for k in own)
+    merged, copied = dict(own), []
+    for k, v in enc.items():
+        kk = ("module." + k) if prefixed else k
+        if kk not in own:
+            raise KeyError(f"pretrained encoder entry {k} has no counterpart in the model")
+        if tuple(own[kk].shape) != tuple(v.shape):
+            raise ValueError(f"pretrained encoder entry {k}: shape {tuple(v.shape)} != model {tuple(own[kk].shape)}")
+        merged[kk] = v
+        copied.append(k)
+    model.load_state_dict(merged)
+    return copied
+
+
 def maybe_resume(conf, model, optimizer, scheduler):
     t = conf["trainer"]
     if not t.get("resume_from_checkpoint", False):
