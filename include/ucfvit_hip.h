@@ -316,6 +316,28 @@ int ucfvit_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dt
  * a matrix uses ceil(rows/64)*ceil(cols/64) tiles; total_tiles = sum. */
 int ucfvit_transpose_batched(const void* src, void* dst, const int64_t* table, int64_t n_mats, int64_t total_tiles, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * UNETR convolutional decoder, HBM-bound part.  Tensors in torch's N C (D) H W layout: `rows` = N*C contiguous rows
+ * of S voxels.  Reference call sites: src/UCF_VIT/simple/arch.py:808-940 (monai UnetResBlock: conv -> instance norm -> LeakyReLU(0.01) ->
+ * conv -> instance norm, + residual, LeakyReLU), training_scripts/train_unetr_simple.py:38 (monai DiceCELoss(to_onehot_y, softmax,
+ * squared_pred)); monai is not vendored: parity is against the plain-torch restatement of these formulas.
+ *
+ * ucfvit_instnorm_fwd:  mean / rstd per row (biased variance, eps), y = lrelu((x - mean) rstd [+ res], slope)   (slope 1: no activation)
+ * ucfvit_instnorm_bwd:  dn = dy (y > 0 ? 1 : slope); dres = dn (if dres); dx = rstd (dn - mean(dn) - n mean(dn n)), n = (x - mean) rstd
+ * workspace: ucfvit_instnorm_workspace(rows, S) bytes (both directions).  S must be a multiple of 16 bytes / element size.
+ * ------------------------------------------------------------------------------------------------------ */
+int64_t ucfvit_instnorm_workspace(int64_t rows, int64_t S);
+int ucfvit_instnorm_fwd(const void* x, const void* res, void* y, float* mean, float* rstd, int64_t rows, int64_t S, float eps, float slope,
+                        void* workspace, int dtype, void* stream);
+int ucfvit_instnorm_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres, int64_t rows,
+                        int64_t S, float slope, void* workspace, int dtype, void* stream);
+/* Dice + cross-entropy of logits [B][n][S] (2 <= n <= 8) against int64 labels [B][S], fused forward + backward:
+ *   p = softmax over the classes; dice_bc = 1 - (2 sum_v p onehot + smooth_nr) / (sum_v p^2 + sum_v onehot + smooth_dr);
+ *   loss = mean_bc dice_bc + mean_bv -log p[label];  dlogits (dtype, may be NULL) = grad_scale * d loss / d logits. */
+int64_t ucfvit_dice_ce_workspace(int64_t B, int64_t S);
+int ucfvit_dice_ce(const void* logits, const int64_t* labels, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S, float smooth_nr,
+                   float smooth_dr, float grad_scale, void* workspace, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -756,7 +756,53 @@ class PatchMSEFn(torch.autograd.Function):
         return dpred * g.to(dpred.dtype), None, None, None
 
 
+class InstNormActFn(torch.autograd.Function):
+    """leaky_relu(instance_norm(x) [+ res], slope) — the normalisation / residual / activation chain of monai's UnetResBlock (reference
+    simple/arch.py:808-940) as two HBM passes forward (statistics, apply) and two backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, eps, slope):
+        xin = x if x.is_contiguous() else x.contiguous()
+        rin = None if res is None else (res if res.is_contiguous() else res.contiguous())
+        y, mean, rstd = ops.instnorm_fwd(xin, rin, eps, slope)
+        ctx.save_for_backward(xin, y, mean, rstd)
+        ctx.slope, ctx.has_res = slope, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd = ctx.saved_tensors
+        d = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dres = ops.instnorm_bwd(d.to(x.dtype), y, x, mean, rstd, ctx.slope, ctx.has_res and ctx.needs_input_grad[1])
+        return dx, dres, None, None
+
+
+class DiceCEFn(torch.autograd.Function):
+    """monai DiceCELoss(to_onehot_y=True, softmax=True, squared_pred=True) (reference train_unetr_simple.py:38), forward + backward fused"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, smooth_nr, smooth_dr):
+        lg = logits if logits.is_contiguous() else logits.contiguous()
+        lb = labels if labels.is_contiguous() else labels.contiguous()
+        loss, dl = ops.dice_ce(lg, lb, smooth_nr, smooth_dr, 1.0, want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g.to(dl.dtype), None, None, None
+
+
 # ---------------------------------------------------------------------------------------------- public helpers
+def instnorm_act(x, res=None, eps=1e-5, slope=0.01):
+    return InstNormActFn.apply(x, res, eps, slope)
+
+
+def dice_ce(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5):
+    return DiceCEFn.apply(logits, labels, smooth_nr, smooth_dr)
+
+
 def cross_entropy(logits, labels):
     return CrossEntropyFn.apply(logits, labels)
 

@@ -71,6 +71,11 @@ SIGNATURES = {
     "ucfvit_adaptive_pos_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
     "ucfvit_adaptive_pos_bwd_workspace": (_I64, [_I64, _I64, _I64, _I, _I, _I]),
     "ucfvit_adaptive_pos_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _I, _P]),
+    "ucfvit_instnorm_workspace": (_I64, [_I64, _I64]),
+    "ucfvit_instnorm_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _F, _P, _I, _P]),
+    "ucfvit_instnorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P, _I, _P]),
+    "ucfvit_dice_ce_workspace": (_I64, [_I64, _I64]),
+    "ucfvit_dice_ce": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _P, _I, _P]),
     "ucfvit_cross_entropy": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P]),
     "ucfvit_mae_mask": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "ucfvit_gather_rows": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),

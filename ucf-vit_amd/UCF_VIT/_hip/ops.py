@@ -519,6 +519,67 @@ def cross_entropy(logits, labels, grad_scale=1.0, want_grad=True):
     return loss, dl, rows
 
 
+# ------------------------------------------------------------------------------------------------ UNETR decoder (HBM-bound part)
+def _rows_view(x):
+    """N C (D) H W tensor -> (rows = N*C, S = voxels per row); contiguous"""
+    _chk(x, "instnorm.x")
+    if x.dim() < 3:
+        raise ValueError("instnorm: expected [N, C, *spatial]")
+    rows = x.shape[0] * x.shape[1]
+    S = x.numel() // max(rows, 1)
+    V = 16 // x.element_size()
+    if S % V:
+        raise ValueError(f"instnorm: the spatial size {S} must be a multiple of {V} elements (16-byte rows); there is no slow path")
+    return rows, S
+
+
+def instnorm_fwd(x, res=None, eps=1e-5, slope=0.01):
+    """y = leaky_relu(instance_norm(x) [+ res], slope) over every (n, c) row (slope 1.0: no activation) -> (y, mean, rstd)"""
+    L = _l.load()
+    rows, S = _rows_view(x)
+    if res is not None:
+        _chk(res, "instnorm.res")
+        if res.shape != x.shape or res.dtype != x.dtype:
+            raise ValueError("instnorm: res must have the shape and dtype of x")
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    ws = workspace(L.ucfvit_instnorm_workspace(rows, S), x.device)
+    _l.check(L.ucfvit_instnorm_fwd(x.data_ptr(), _p(res), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, S, eps, slope, ws.data_ptr(), dt(x),
+                                   _stream()), "ucfvit_instnorm_fwd")
+    return y, mean, rstd
+
+
+def instnorm_bwd(dy, y, x, mean, rstd, slope, want_dres):
+    L = _l.load()
+    rows, S = _rows_view(x)
+    _chk(dy, "instnorm_bwd.dy")
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    ws = workspace(L.ucfvit_instnorm_workspace(rows, S), x.device)
+    _l.check(L.ucfvit_instnorm_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), rows, S,
+                                   slope, ws.data_ptr(), dt(x), _stream()), "ucfvit_instnorm_bwd")
+    return dx, dres
+
+
+def dice_ce(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5, grad_scale=1.0, want_grad=True):
+    """logits [B, n, *spatial] (2 <= n <= 8), labels int64 [B, *spatial] (or [B, 1, *spatial]) -> (loss fp32 scalar, dlogits or None)"""
+    L = _l.load()
+    _chk(logits, "dice_ce.logits"), _chk(labels, "dice_ce.labels")
+    if labels.dtype != torch.int64:
+        raise TypeError("dice_ce: labels must be int64")
+    B, n = logits.shape[0], logits.shape[1]
+    S = logits.numel() // (B * n)
+    if labels.numel() != B * S:
+        raise ValueError("dice_ce: labels must hold one class index per voxel")
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    ws = workspace(L.ucfvit_dice_ce_workspace(B, S), logits.device)
+    _l.check(L.ucfvit_dice_ce(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dl), B, n, S, smooth_nr, smooth_dr, grad_scale, ws.data_ptr(),
+                              dt(logits), _stream()), "ucfvit_dice_ce")
+    return loss, dl
+
+
 # ------------------------------------------------------------------------------------------------ MAE
 def mae_mask(noise, len_keep):
     L = _l.load()

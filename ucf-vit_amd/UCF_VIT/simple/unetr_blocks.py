@@ -2,11 +2,14 @@
 1x1 output conv).  In the reference these come from the un-vendored dependency monai>=1.4.0 (UnetrBasicBlock, UnetrPrUpBlock,
 UnetrUpBlock, UnetOutBlock; src/UCF_VIT/simple/arch.py:33-34,808-940): the classes below restate that published block
 structure and its state_dict naming so checkpoints line up.  PARITY UNPINNED: monai is not installed in the build container
-and the reference ships no fixtures for it.  The arithmetic stays on torch/MIOpen — the conv decoder is outside
-the round-1 HIP hot path; only the transformer encoder of UNETR runs on libucfvit_hip.so.
+and the reference ships no fixtures for it.  Round 2 (partial): the instance norms with the
+LeakyReLU / residual add that follow them are fused HIP kernels (csrc/unetr_decoder.hip, two HBM passes each way instead of torch's chain
+of element-wise kernels), and the Dice + CE loss is one; the 3x3(x3) and transposed convolutions themselves still run on torch/MIOpen.
 """
 import torch
 import torch.nn as nn
+
+from UCF_VIT._hip import functional as HF
 
 
 def _conv(nd, cin, cout, k, s, transposed=False, bias=False):
@@ -35,10 +38,14 @@ class UnetResBlock(nn.Module):
             self.norm3 = _inorm(nd, out_channels)
 
     def forward(self, inp):
-        out = self.lrelu(self.norm1(self.conv1(inp)))
-        out = self.norm2(self.conv2(out))
-        residual = self.norm3(self.conv3(inp)) if self.downsample else inp
-        return self.lrelu(out + residual)
+        if not inp.is_cuda:
+            raise RuntimeError("UnetResBlock: the normalisation / activation kernels run on the MI355X only; there is no CPU path")
+        # convolutions on MIOpen; every instance norm with what follows it (LeakyReLU, residual add + LeakyReLU) is ONE fused HIP op
+        ns = self.lrelu.negative_slope
+        out = HF.instnorm_act(self.conv1(inp), None, self.norm1.eps, ns)
+        out = self.conv2(out)
+        residual = HF.instnorm_act(self.conv3(inp), None, self.norm3.eps, 1.0) if self.downsample else inp
+        return HF.instnorm_act(out, residual, self.norm2.eps, ns)
 
 
 class UnetrBasicBlock(nn.Module):
