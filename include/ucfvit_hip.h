@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 7
+#define UCFVIT_ABI_VERSION 8
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -337,6 +337,47 @@ int ucfvit_instnorm_bwd(const void* dy, const void* y, const void* x, const floa
 int64_t ucfvit_dice_ce_workspace(int64_t B, int64_t S);
 int ucfvit_dice_ce(const void* logits, const int64_t* labels, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S, float smooth_nr,
                    float smooth_dr, float grad_scale, void* workspace, int dtype, void* stream);
+
+/* The same loss on strided logits: element (b, class c, voxel i) at logits[b stride_b + c stride_c + i stride_s] (dlogits alike).
+ * N C (D) H W is (n S, S, 1); a channels-last tensor whose voxel rows are ld apart is (S ld, 1, ld). */
+int ucfvit_dice_ce_strided(const void* logits, const int64_t* labels, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S,
+                           int64_t stride_b, int64_t stride_c, int64_t stride_s, float smooth_nr, float smooth_dr, float grad_scale,
+                           void* workspace, int dtype, void* stream);
+
+/* Channels-last instance norm (+ LeakyReLU, + residual) for the layout of the convolution kernels below: x, res, y [B][S][C] bf16,
+ * mean / rstd [B][C] fp32; C a power of two in 8..2048.  Same formulas as ucfvit_instnorm_fwd / _bwd. */
+int64_t ucfvit_instnorm_cl_workspace(int64_t B, int64_t S, int64_t C);
+int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, float eps,
+                           float slope, void* workspace, void* stream);
+int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres, int64_t B,
+                           int64_t S, int64_t C, float slope, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * UNETR convolutional decoder, convolutions.  Reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai's
+ * blocks are chains of Conv3d(kernel 3, stride 1, padding 1, no bias) and ConvTranspose3d(kernel 2, stride 2, no bias); these entry
+ * points replace torch.nn.functional.conv3d / conv_transpose3d (MIOpen) under them.
+ * Activations are channels-last bf16 [B][X][Y][Z][C] (= torch.channels_last_3d memory of an [B, C, X, Y, Z] tensor).
+ *
+ * ucfvit_conv3d_fwd: y[v][co] = sum_{tap, ci} w[co][ci][tap] x[v + tap - 1][ci] (zero outside the volume), fp32 accumulation on MFMA.
+ *   Cin in {8, 16, 32 k}, Cout = 16 k.  w_packed (bf16) holds the weights per 32-wide contraction step: with CPC = min(Cin, 32),
+ *   TPS = 32 / CPC taps per step and NTS = ceil(27 / TPS) steps per channel chunk, w_packed[cc][ts][co][kk] = w[co][cc CPC + kk % CPC][tap]
+ *   for tap = ts TPS + kk / CPC (zero when tap > 26); tap = (dx 3 + dy) 3 + dz.  The data gradient is the same call on dy with the
+ *   flipped, transposed weights.
+ * ucfvit_conv3d_wgrad: dw[tap][co][ci] = sum_v dy[v][co] x[v + tap - 1][ci] in fp32, written as [Cout / (16 MB)][Cin / CPC][27][16 MB][max(CPC, 16)]
+ *   with MB = 2 when Cout % 32 == 0, else 1 (ucfvit_conv3d_wgrad_size floats; for CPC = 8 columns 8..15 are scratch).
+ *   workspace: ucfvit_conv3d_wgrad_workspace bytes (per-workgroup partials, folded in a fixed order: deterministic).
+ * ucfvit_depth_to_space2: the transposed convolution is the GEMM x[V][Cin] * w[Cin][8 Cout] followed by this shuffle of
+ *   cols [B Xi Yi Zi][(dx, dy, dz)][C] into out [B][2 Xi][2 Yi][2 Zi][C] (to_space = 1) — or its inverse for the backward pass (0).
+ * ucfvit_pad_channels8: fp32 [V] -> bf16 [V][8] (channels 1..7 zero): the one-channel input volume as an operand of the kernels above.
+ * ------------------------------------------------------------------------------------------------------ */
+int ucfvit_conv3d_fwd(const void* x, const void* w_packed, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout,
+                      void* stream);
+int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout);
+int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout);
+int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y, int64_t Z,
+                        int64_t Cin, int64_t Cout, void* stream);
+int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int to_space, void* stream);
+int ucfvit_pad_channels8(const float* src, void* dst, int64_t V, void* stream);
 
 #ifdef __cplusplus
 }

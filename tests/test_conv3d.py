@@ -1,0 +1,199 @@
+"""Convolution kernels of the UNETR decoder (csrc/conv3d.hip, UCF_VIT/_hip/conv.py) against torch.nn.functional on the same bf16-rounded
+operands (fp32 math on the device: the checker, not the product).  monai — where the reference gets these layers — is absent: PARITY UNPINNED
+against it; what is pinned here is the layer semantics monai documents: Conv3d(k=3, s=1, p=1, bias=False),
+ConvTranspose3d(k=2, s=2, bias=False), InstanceNorm3d(affine=False) + LeakyReLU(0.01)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _cl(t):           # [B, C, X, Y, Z] -> channels-last [B, X, Y, Z, C]
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _ncdhw(t):
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
+
+
+def test_pack_and_unpack_are_inverse_layouts():
+    """CPU: the packed forward layout puts w[co, ci, tap] at [chunk][step][co][(tap % TPS) CPC + ci % CPC]; unpack inverts the wgrad layout"""
+    from UCF_VIT._hip import conv
+    for cin, cout in ((8, 16), (16, 16), (32, 16), (64, 32), (128, 64)):
+        w = torch.randn(cout, cin, 3, 3, 3)
+        p = conv.pack_conv3_weight(w).float()
+        cpc = min(cin, 32)
+        tps = 32 // cpc
+        for (co, ci, tap) in ((0, 0, 0), (cout - 1, cin - 1, 26), (3, cin // 2, 13), (5, 1, 7)):
+            ref = w.reshape(cout, cin, 27)[co, ci, tap].bfloat16().float()
+            got = p[ci // cpc, tap // tps, co, (tap % tps) * cpc + ci % cpc]
+            assert got == ref
+        if tps > 1:                                              # the padding taps hold zeros
+            assert p[0, -1, :, (27 % tps) * cpc:].abs().max() == 0
+        mb16, nbk16 = (32 if cout % 32 == 0 else 16), max(cpc, 16)
+        packed = torch.arange((cout // mb16) * (cin // cpc) * 27 * mb16 * nbk16, dtype=torch.float32)
+        u = conv.unpack_conv3_wgrad(packed, cin, cout)
+        co, ci, tap = cout - 2, cin - 3, 11
+        idx = ((((co // mb16) * (cin // cpc) + ci // cpc) * 27 + tap) * mb16 + co % mb16) * nbk16 + ci % cpc
+        assert u.reshape(cout, cin, 27)[co, ci, tap] == packed[idx]
+
+
+CONV_CASES = [
+    # B, X, Y, Z, Cin, Cout: ragged extents (tile overhang on every axis), every channel-count path of the decoder
+    (2, 5, 9, 21, 8, 16),
+    (1, 4, 8, 16, 16, 16),
+    (2, 3, 10, 33, 32, 16),
+    (1, 6, 7, 18, 16, 32),
+    (1, 4, 9, 16, 32, 32),
+    (1, 5, 4, 20, 64, 32),
+    (1, 4, 6, 16, 64, 64),
+    (1, 3, 5, 16, 128, 64),
+    (1, 2, 4, 16, 256, 128),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,X,Y,Z,cin,cout", CONV_CASES)
+def test_conv3x3x3_forward_and_gradients(B, X, Y, Z, cin, cout):
+    from UCF_VIT._hip import conv
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(B, cin, X, Y, Z, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5).cuda()
+    dy = torch.randn(B, cout, X, Y, Z, generator=g).bfloat16().cuda()
+    xr, wr = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True)
+    yr = F.conv3d(xr, wr, padding=1)
+    yr.backward(dy.float())
+    want_dx = cin % 16 == 0                               # the 8-channel operand is the zero-padded input volume: it never needs a gradient
+    xc = _cl(x).requires_grad_(want_dx)
+    wp = w.clone().requires_grad_(True)
+    y = conv.conv3x3x3(xc, wp)
+    assert y.shape == (B, X, Y, Z, cout) and y.dtype == torch.bfloat16
+    y.backward(_cl(dy))
+    assert _rel(_ncdhw(y), yr) < 1e-2                     # bf16 output rounding (2^-8) of an fp32-accumulated sum
+    if want_dx:
+        assert _rel(_ncdhw(xc.grad), xr.grad) < 1e-2
+    assert _rel(wp.grad, wr.grad) < 2e-3                  # fp32 out
+    # deterministic
+    xc2 = _cl(x).requires_grad_(want_dx)
+    wp2 = w.clone().requires_grad_(True)
+    y2 = conv.conv3x3x3(xc2, wp2)
+    y2.backward(_cl(dy))
+    assert torch.equal(y, y2) and torch.equal(wp.grad, wp2.grad) and (not want_dx or torch.equal(xc.grad, xc2.grad))
+
+
+@pytest.mark.gpu
+def test_conv3x3x3_single_channel_input_through_the_padded_operand():
+    from UCF_VIT._hip import conv, ops
+    g = torch.Generator().manual_seed(3)
+    vol = torch.randn(2, 6, 9, 20, generator=g).cuda()
+    w = (torch.randn(16, 1, 3, 3, 3, generator=g) * 0.2).cuda().requires_grad_(True)
+    x8 = ops.pad_channels8(vol)
+    assert x8.shape == (2, 6, 9, 20, 8) and torch.equal(x8[..., 0].float(), vol.bfloat16().float()) and x8[..., 1:].abs().max() == 0
+    y = conv.conv3x3x3(x8, w)
+    dy = torch.randn(y.shape, generator=g).bfloat16().cuda()
+    y.backward(dy)
+    wr = w.detach().bfloat16().float().requires_grad_(True)
+    yr = F.conv3d(vol.bfloat16().float()[:, None], wr, padding=1)
+    yr.backward(_ncdhw(dy).float())
+    assert _rel(_ncdhw(y), yr) < 1e-2
+    assert w.grad.shape == (16, 1, 3, 3, 3) and _rel(w.grad, wr.grad) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,X,Y,Z,cin,cout", [(2, 3, 4, 5, 768, 128), (1, 4, 4, 4, 128, 64), (1, 5, 6, 7, 32, 16), (1, 2, 3, 4, 768, 32)])
+def test_tconv2x2x2_forward_and_gradients(B, X, Y, Z, cin, cout):
+    from UCF_VIT._hip import conv
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, X, Y, Z, generator=g).bfloat16().cuda()
+    w = (torch.randn(cin, cout, 2, 2, 2, generator=g) * cin ** -0.5).cuda()
+    dy = torch.randn(B, cout, 2 * X, 2 * Y, 2 * Z, generator=g).bfloat16().cuda()
+    xr, wr = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, stride=2)
+    yr.backward(dy.float())
+    xc, wp = _cl(x).requires_grad_(True), w.clone().requires_grad_(True)
+    y = conv.tconv2x2x2(xc, wp)
+    assert y.shape == (B, 2 * X, 2 * Y, 2 * Z, cout)
+    y.backward(_cl(dy))
+    assert _rel(_ncdhw(y), yr) < 1e-2
+    assert _rel(_ncdhw(xc.grad), xr.grad) < 1e-2
+    assert _rel(wp.grad, wr.grad) < 2e-3
+
+
+@pytest.mark.gpu
+def test_depth_to_space_round_trip_is_exact():
+    from UCF_VIT._hip import ops
+    cols = torch.randn(2 * 3 * 4 * 5, 8 * 16).bfloat16().cuda()
+    y = ops.depth_to_space2(cols, 2, 3, 4, 5, 16)
+    ref = cols.view(2, 3, 4, 5, 2, 2, 2, 16).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(2, 6, 8, 10, 16)
+    assert torch.equal(y, ref)
+    assert torch.equal(ops.space_to_depth2(y), cols)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,bias,fp32", [(16, 4, True, True), (32, 16, False, False), (8, 16, False, False), (256, 128, False, False)])
+def test_conv1x1x1_forward_and_gradients(cin, cout, bias, fp32):
+    from UCF_VIT._hip import conv
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(2, cin, 4, 5, 6, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, cin, 1, 1, 1, generator=g) * cin ** -0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda() if bias else None
+    dy = torch.randn(2, cout, 4, 5, 6, generator=g).bfloat16().cuda()
+    xr, wr = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True)
+    br = b.bfloat16().float().requires_grad_(True) if bias else None
+    yr = F.conv3d(xr, wr, br)
+    yr.backward(dy.float())
+    xc, wp = _cl(x).requires_grad_(True), w.clone().requires_grad_(True)
+    bp = b.clone().requires_grad_(True) if bias else None
+    y = conv.conv1x1x1(xc, wp, bp, out_fp32=fp32)
+    assert y.shape == (2, 4, 5, 6, cout) and y.dtype == (torch.float32 if fp32 else torch.bfloat16)
+    y.backward(_cl(dy).to(y.dtype))
+    assert _rel(_ncdhw(y), yr) < (1e-4 if fp32 else 1e-2)
+    assert _rel(_ncdhw(xc.grad), xr.grad) < 1e-2
+    assert _rel(wp.grad, wr.grad) < 2e-3
+    if bias:
+        assert _rel(bp.grad, br.grad) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,with_res,slope", [(16, False, 0.01), (16, True, 0.01), (32, True, 0.01), (128, False, 1.0), (8, True, 0.01)])
+def test_instnorm_channels_last_equals_the_row_layout_kernels_and_torch(C, with_res, slope):
+    from UCF_VIT._hip import conv
+    g = torch.Generator().manual_seed(C)
+    B, dims = 2, (6, 10, 37)
+    x = (torch.randn(B, C, *dims, generator=g) * 2 + 0.5).bfloat16().cuda()
+    res = torch.randn(B, C, *dims, generator=g).bfloat16().cuda() if with_res else None
+    dy = torch.randn(B, C, *dims, generator=g).bfloat16().cuda()
+    xr = x.float().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if with_res else None
+    n = F.instance_norm(xr, eps=1e-5)
+    yr = F.leaky_relu(n + rr if with_res else n, slope)
+    yr.backward(dy.float())
+    xc = _cl(x).requires_grad_(True)
+    rc = _cl(res).requires_grad_(True) if with_res else None
+    y = conv.instnorm_act_cl(xc, rc, 1e-5, slope)
+    y.backward(_cl(dy))
+    assert _rel(_ncdhw(y), yr) < 1e-2
+    assert _rel(_ncdhw(xc.grad), xr.grad) < 2e-2
+    if with_res:
+        assert _rel(_ncdhw(rc.grad), rr.grad) < 1e-2
+
+
+@pytest.mark.gpu
+def test_dice_ce_on_a_channels_last_view_equals_the_contiguous_call():
+    from UCF_VIT._hip import ops
+    g = torch.Generator().manual_seed(5)
+    B, n, dims, ld = 2, 4, (5, 6, 7), 8
+    buf = torch.randn(B, *dims, ld, generator=g).cuda()
+    labels = torch.randint(0, n, (B, *dims), generator=g).cuda()
+    view = buf[..., :n].permute(0, 4, 1, 2, 3)                   # [B, n, X, Y, Z] over channels-last memory with padded rows
+    assert not view.is_contiguous()
+    loss_v, dl_v = ops.dice_ce(view, labels)
+    loss_c, dl_c = ops.dice_ce(view.contiguous(), labels)
+    assert torch.equal(loss_v, loss_c)
+    assert dl_v.shape == view.shape and dl_v.stride() == view.stride()
+    assert torch.equal(dl_v.contiguous(), dl_c)
+    with pytest.raises(RuntimeError):
+        ops.dice_ce(buf[..., :n].permute(0, 4, 3, 2, 1), labels)

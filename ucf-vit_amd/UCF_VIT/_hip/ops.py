@@ -563,21 +563,146 @@ def instnorm_bwd(dy, y, x, mean, rstd, slope, want_dres):
 
 
 def dice_ce(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5, grad_scale=1.0, want_grad=True):
-    """logits [B, n, *spatial] (2 <= n <= 8), labels int64 [B, *spatial] (or [B, 1, *spatial]) -> (loss fp32 scalar, dlogits or None)"""
+    """logits [B, n, *spatial] (2 <= n <= 8), labels int64 [B, *spatial] (or [B, 1, *spatial]) -> (loss fp32 scalar, dlogits or None).
+    logits may be contiguous (N C D H W) or a channels-last view of a [B, *spatial, ld >= n] buffer (what the HIP decoder returns)."""
     L = _l.load()
-    _chk(logits, "dice_ce.logits"), _chk(labels, "dice_ce.labels")
+    _chk(labels, "dice_ce.labels")
+    if not logits.is_cuda:
+        _chk(logits, "dice_ce.logits")
     if labels.dtype != torch.int64:
         raise TypeError("dice_ce: labels must be int64")
     B, n = logits.shape[0], logits.shape[1]
     S = logits.numel() // (B * n)
     if labels.numel() != B * S:
         raise ValueError("dice_ce: labels must hold one class index per voxel")
+    if logits.is_contiguous():
+        sb, sc, ss = n * S, S, 1
+        dl = torch.empty_like(logits) if want_grad else None
+    else:
+        cl = logits.movedim(1, -1)                           # [B, *spatial, n]
+        ld = cl.stride(-2)
+        ok = cl.stride(-1) == 1 and ld >= n and cl.stride(0) == S * ld
+        exp = ld
+        for d in range(cl.dim() - 2, 0, -1):
+            ok = ok and cl.stride(d) == exp
+            exp *= cl.shape[d]
+        if not ok:
+            raise RuntimeError("dice_ce: logits must be contiguous or a channels-last view with contiguous voxel rows")
+        sb, sc, ss = S * ld, 1, ld
+        dl = torch.zeros(B * S * ld, dtype=logits.dtype, device=logits.device).as_strided(logits.shape, logits.stride()) if want_grad else None
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
-    dl = torch.empty_like(logits) if want_grad else None
     ws = workspace(L.ucfvit_dice_ce_workspace(B, S), logits.device)
-    _l.check(L.ucfvit_dice_ce(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dl), B, n, S, smooth_nr, smooth_dr, grad_scale, ws.data_ptr(),
-                              dt(logits), _stream()), "ucfvit_dice_ce")
+    _l.check(L.ucfvit_dice_ce_strided(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dl), B, n, S, sb, sc, ss, smooth_nr, smooth_dr,
+                                      grad_scale, ws.data_ptr(), dt(logits), _stream()), "ucfvit_dice_ce")
     return loss, dl
+
+
+# ------------------------------------------------------------------------------------------------ UNETR decoder, channels-last bf16
+def _chk_cl(t, name, C=None):
+    _chk(t, name)
+    if t.dtype != torch.bfloat16 or t.dim() != 5:
+        raise TypeError(f"{name}: expected a channels-last bf16 tensor [B, X, Y, Z, C], got {tuple(t.shape)} {t.dtype}")
+    if C is not None and t.shape[-1] != C:
+        raise ValueError(f"{name}: expected {C} channels, got {t.shape[-1]}")
+    return t
+
+
+def conv3d_fwd(x, w_packed, cout):
+    """x [B, X, Y, Z, Cin] bf16, w_packed from conv.pack_conv3_weight -> y [B, X, Y, Z, cout] bf16 (3x3x3, stride 1, zero padding 1)"""
+    L = _l.load()
+    _chk_cl(x, "conv3d.x"), _chk(w_packed, "conv3d.w_packed")
+    B, X, Y, Z, cin = x.shape
+    if w_packed.dtype != torch.bfloat16 or w_packed.numel() != (cin // min(cin, 32)) * (-(-27 // (32 // min(cin, 32)))) * cout * 32:
+        raise ValueError("conv3d: w_packed does not match (Cin, Cout)")
+    y = torch.empty((B, X, Y, Z, cout), dtype=torch.bfloat16, device=x.device)
+    _l.check(L.ucfvit_conv3d_fwd(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, X, Y, Z, cin, cout, _stream()), "ucfvit_conv3d_fwd")
+    return y
+
+
+def conv3d_wgrad(x, dy):
+    """-> packed fp32 weight gradient (conv.unpack_conv3_wgrad turns it into [Cout, Cin, 3, 3, 3])"""
+    L = _l.load()
+    _chk_cl(x, "conv3d_wgrad.x"), _chk_cl(dy, "conv3d_wgrad.dy")
+    B, X, Y, Z, cin = x.shape
+    cout = dy.shape[-1]
+    if dy.shape[:4] != x.shape[:4]:
+        raise ValueError("conv3d_wgrad: x and dy must cover the same voxels")
+    n = L.ucfvit_conv3d_wgrad_size(cin, cout)
+    nbytes = L.ucfvit_conv3d_wgrad_workspace(B, X, Y, Z, cin, cout)
+    if n <= 0 or nbytes <= 0:
+        raise ValueError(f"conv3d_wgrad: unsupported channel counts Cin={cin} Cout={cout}")
+    dw = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = workspace(nbytes, x.device)
+    _l.check(L.ucfvit_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, cin, cout, _stream()),
+             "ucfvit_conv3d_wgrad")
+    return dw
+
+
+def depth_to_space2(cols, B, Xi, Yi, Zi, C):
+    """cols [B Xi Yi Zi, 8 C] (column blocks (dx, dy, dz)) -> [B, 2Xi, 2Yi, 2Zi, C]"""
+    L = _l.load()
+    _chk(cols, "depth_to_space2.cols")
+    if cols.dtype != torch.bfloat16 or cols.numel() != B * Xi * Yi * Zi * 8 * C:
+        raise ValueError("depth_to_space2: bad operand")
+    out = torch.empty((B, 2 * Xi, 2 * Yi, 2 * Zi, C), dtype=torch.bfloat16, device=cols.device)
+    _l.check(L.ucfvit_depth_to_space2(cols.data_ptr(), out.data_ptr(), B, Xi, Yi, Zi, C, 1, _stream()), "ucfvit_depth_to_space2")
+    return out
+
+
+def space_to_depth2(y):
+    """[B, 2Xi, 2Yi, 2Zi, C] -> [B Xi Yi Zi, 8 C]"""
+    L = _l.load()
+    _chk_cl(y, "space_to_depth2.y")
+    B, X2, Y2, Z2, C = y.shape
+    if X2 % 2 or Y2 % 2 or Z2 % 2:
+        raise ValueError("space_to_depth2: extents must be even")
+    Xi, Yi, Zi = X2 // 2, Y2 // 2, Z2 // 2
+    cols = torch.empty((B * Xi * Yi * Zi, 8 * C), dtype=torch.bfloat16, device=y.device)
+    _l.check(L.ucfvit_depth_to_space2(y.data_ptr(), cols.data_ptr(), B, Xi, Yi, Zi, C, 0, _stream()), "ucfvit_depth_to_space2")
+    return cols
+
+
+def pad_channels8(vol):
+    """fp32 [B, X, Y, Z] -> bf16 [B, X, Y, Z, 8], channel 0 = the volume, channels 1..7 zero"""
+    L = _l.load()
+    _chk(vol, "pad_channels8.vol")
+    if vol.dtype != torch.float32 or vol.dim() != 4:
+        raise TypeError("pad_channels8: expected an fp32 [B, X, Y, Z] volume")
+    out = torch.empty(tuple(vol.shape) + (8,), dtype=torch.bfloat16, device=vol.device)
+    _l.check(L.ucfvit_pad_channels8(vol.data_ptr(), out.data_ptr(), vol.numel(), _stream()), "ucfvit_pad_channels8")
+    return out
+
+
+def instnorm_cl_fwd(x, res=None, eps=1e-5, slope=0.01):
+    """channels-last: y = leaky_relu(instance_norm(x) [+ res], slope) per (batch, channel) -> (y, mean [B, C], rstd [B, C])"""
+    L = _l.load()
+    _chk_cl(x, "instnorm_cl.x")
+    if res is not None:
+        _chk_cl(res, "instnorm_cl.res")
+        if res.shape != x.shape:
+            raise ValueError("instnorm_cl: res must have the shape of x")
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
+    _l.check(L.ucfvit_instnorm_cl_fwd(x.data_ptr(), _p(res), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, S, C, eps, slope, ws.data_ptr(),
+                                      _stream()), "ucfvit_instnorm_cl_fwd")
+    return y, mean, rstd
+
+
+def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres):
+    L = _l.load()
+    _chk_cl(dy, "instnorm_cl_bwd.dy"), _chk_cl(x, "instnorm_cl_bwd.x")
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
+    _l.check(L.ucfvit_instnorm_cl_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), B, S, C,
+                                      slope, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd")
+    return dx, dres
 
 
 # ------------------------------------------------------------------------------------------------ MAE

@@ -1,0 +1,439 @@
+// Convolutions of the UNETR decoder for gfx950: 3x3x3 (stride 1, zero padding 1) as an implicit GEMM on
+// v_mfma_f32_16x16x32_bf16, plus the data movers of the 2x2x2 stride-2 transposed convolution (which itself is a plain GEMM).
+//
+//   reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai UnetrBasicBlock / UnetrPrUpBlock / UnetrUpBlock are chains of
+//   Conv3d(k=3, s=1, p=1, bias=False) and ConvTranspose3d(k=2, s=2, bias=False).  monai is absent from the build container (PARITY UNPINNED
+//   against it); the oracle is torch.nn.functional.conv3d / conv_transpose3d on the same bf16-rounded operands (tests/test_conv3d.py).
+//
+// Layout: activations are CHANNELS-LAST bf16, [B][X][Y][Z][C] — a voxel's channel vector is contiguous, so the encoder's token matrices
+// [B, N, D] ARE decoder inputs without a permute, an MFMA operand fragment (8 channels of one voxel) is one 16-byte load, and an output
+// block of 16 voxels x 16 channels is one contiguous 512-byte run.  Weights arrive pre-packed per 32-wide contraction step (see
+// UCF_VIT/_hip/conv.py:pack_conv3_weight): step s of channel chunk cc holds, for every output channel, 32 values over (tap, ci).
+//
+// forward / data gradient (same kernel; the data gradient is the convolution of dy with the flipped, transposed weights):
+//   one workgroup = TX x TY x 16 output voxels x 16 NB output channels.  The (TX+2)(TY+2)(18) halo of the input chunk (<= 32 channels)
+//   is staged in LDS once and read 27 times (once per tap) as the B operand; the weight slab of the chunk is staged next to it (A operand).
+//   D[co][voxel] -> each lane holds 4 consecutive output channels of one voxel: 8-byte stores, 512 B contiguous per 16 x 16 block.
+//   algorithmic HBM bytes per output voxel: 2 Cin (read once; the halo re-reads are L2 hits) + 2 Cout.
+// weight gradient: dW[tap][co][ci] = sum_v dy[v][co] x[v + tap][ci]: contraction over voxels, so both operands come out of their
+//   voxel-major LDS images through ds_read_b64_tr_b16 (hardware transpose).  A workgroup walks a range of voxel tiles with the 27 x
+//   (Cout/16) x (Cin/16) accumulator blocks spread over its 4 waves (7 taps each), and writes ONE partial per workgroup; the partials are
+//   folded by ucfvit_reduce_rows in a fixed order (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int CT = 256;
+typedef bf16x8 frag_t;
+
+__device__ __forceinline__ f32x4 mma(const frag_t& a, const frag_t& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int CPC> struct CG {                        // CPC = channels per contraction chunk (8, 16 or 32)
+    static constexpr int TPS = 32 / CPC;              // taps folded into one 32-wide MFMA step
+    static constexpr int NTS = (27 + TPS - 1) / TPS;  // MFMA steps per chunk (27, 14, 7)
+    static constexpr int VS = CPC * 2;                // bytes per voxel in the LDS image
+    static constexpr int PPV = VS / 16;               // 16-byte pieces per voxel
+};
+
+struct ConvGeo {
+    int B, X, Y, Z, Cin, Cout;
+    int tx, ty, tz;      // tile counts along x, y, z
+    int tiles;           // B tx ty tz
+};
+
+// 16-byte load of 8 channels of voxel (b, gx, gy, gz), zero outside the volume (= the convolution's zero padding)
+__device__ __forceinline__ u32x4 load_voxel(const bf16* __restrict__ x, const ConvGeo& g, int b, int gx, int gy, int gz, int C, int ch) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned)gx < (unsigned)g.X && (unsigned)gy < (unsigned)g.Y && (unsigned)gz < (unsigned)g.Z)
+        v = *reinterpret_cast<const u32x4*>(x + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * C + ch);
+    return v;
+}
+
+template <int CPC, int HX, int HY, int HZ>
+__device__ __forceinline__ void stage_halo(char* halo, const bf16* __restrict__ x, const ConvGeo& g, int b, int x0, int y0, int z0, int ch0,
+                                           int tid) {
+    typedef CG<CPC> G;
+    constexpr int NP = HX * HY * HZ * G::PPV;
+    for (int p = tid; p < NP; p += CT) {
+        const int hv = p / G::PPV, piece = p % G::PPV;
+        const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+        *reinterpret_cast<u32x4*>(halo + hv * G::VS + piece * 16) =
+            load_voxel(x, g, b, x0 + hx - 1, y0 + hy - 1, z0 + hz - 1, g.Cin, ch0 + piece * 8);
+    }
+}
+
+__device__ __forceinline__ void decode_tile(const ConvGeo& g, int t, int& b, int& ix, int& iy, int& iz) {
+    iz = t % g.tz;
+    t /= g.tz;
+    iy = t % g.ty;
+    t /= g.ty;
+    ix = t % g.tx;
+    b = t / g.tx;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward / data gradient
+template <int CPC, int NB, int TX, int TY>
+__global__ __launch_bounds__(CT) void conv3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, bf16* __restrict__ y,
+                                                       ConvGeo g) {
+    typedef CG<CPC> G;
+    constexpr int HX = TX + 2, HY = TY + 2, HZ = 18;
+    constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
+    constexpr int CB = 16 * NB;                     // output channels per workgroup
+    constexpr int RPW = TX * TY / 4;                // 16-voxel rows per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wl = smem + HALO_BYTES;                   // [NTS][CB][32] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    int b, ix, iy, iz;
+    decode_tile(g, xcd_remap(blockIdx.x, gridDim.x), b, ix, iy, iz);
+    const int x0 = ix * TX, y0 = iy * TY, z0 = iz * 16;
+    const int co0 = blockIdx.y * CB;
+    f32x4 acc[RPW][NB];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nchunks = g.Cin / CPC;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc) __syncthreads();
+        stage_halo<CPC, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cc * CPC, tid);
+        for (int p = tid; p < G::NTS * CB * 4; p += CT) {
+            const int piece = p & 3, row = (p >> 2) % CB, ts = (p >> 2) / CB;
+            *reinterpret_cast<u32x4*>(wl + p * 16) =
+                *reinterpret_cast<const u32x4*>(wp + ((int64_t)(cc * G::NTS + ts) * g.Cout + co0 + row) * 32 + piece * 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ts = 0; ts < G::NTS; ++ts) {
+            frag_t a[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const frag_t*>(wl + ((ts * CB + nb * 16 + li) * 64 + lg * 16));
+            int tap, chb;                                       // the tap and channel byte offset this lane's 8 contraction values cover
+            if (CPC == 32) {
+                tap = ts;
+                chb = lg * 16;
+            } else if (CPC == 16) {
+                tap = 2 * ts + (lg >> 1);
+                chb = (lg & 1) * 16;
+            } else {
+                tap = 4 * ts + lg;
+                chb = 0;
+            }
+            if (tap > 26) tap = 26;                             // padding step: its weights are zero, read any staged voxel
+            const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+            const int boff = ((dx * HY + dy) * HZ + dz + li) * G::VS + chb;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, xl = row / TY, yl = row % TY;
+                const frag_t bf = *reinterpret_cast<const frag_t*>(halo + boff + (xl * HY + yl) * HZ * G::VS);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = mma(a[nb], bf, acc[r][nb]);
+            }
+        }
+    }
+    // D[co = 4 lg + e][voxel = li]
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
+        if (gx < g.X && gy < g.Y && gz < g.Z) {
+            bf16* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.Cout + co0 + lg * 4;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[r][nb][e];
+                *reinterpret_cast<bf16x4*>(yp + nb * 16) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- weight gradient
+constexpr int TZW = 32;       // z extent of a weight-gradient tile = one 32-deep contraction step per (x, y) row
+constexpr int WTAPS = 7;      // taps per wave (wave w owns taps w, w + 4, ...)
+
+template <int CPC, int MB, int TX, int TY>
+__global__ __launch_bounds__(CT) void conv3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ part,
+                                                         ConvGeo g, int tiles_per_wg) {
+    typedef CG<CPC> G;
+    constexpr int HX = TX + 2, HY = TY + 2, HZ = TZW + 2;
+    constexpr int NBK = CPC >= 16 ? CPC / 16 : 1;
+    constexpr int VSD = 32 * MB;                    // bytes per voxel of the dy image (16 MB channels)
+    constexpr int DY_BYTES = TX * TY * TZW * VSD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* dyt = smem;
+    char* halo = smem + DY_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4, q = li >> 2, p4 = li & 3;
+    const int cin_chunks = g.Cin / CPC;
+    const int cib = blockIdx.y % cin_chunks, cob = blockIdx.y / cin_chunks;
+    f32x4 acc[WTAPS][MB][NBK];
+#pragma unroll
+    for (int k = 0; k < WTAPS; ++k)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) acc[k][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t_lo = blockIdx.x * tiles_per_wg, t_hi = min(g.tiles, t_lo + tiles_per_wg);
+    for (int t = t_lo; t < t_hi; ++t) {
+        int b, ix, iy, iz;
+        decode_tile(g, t, b, ix, iy, iz);
+        const int x0 = ix * TX, y0 = iy * TY, z0 = iz * TZW;
+        __syncthreads();
+        constexpr int DPV = VSD / 16;
+        for (int p = tid; p < TX * TY * TZW * DPV; p += CT) {
+            const int v = p / DPV, piece = p % DPV;
+            const int zl = v % TZW, yl = (v / TZW) % TY, xl = v / (TZW * TY);
+            *reinterpret_cast<u32x4*>(dyt + v * VSD + piece * 16) =
+                load_voxel(dy, g, b, x0 + xl, y0 + yl, z0 + zl, g.Cout, cob * 16 * MB + piece * 8);
+        }
+        stage_halo<CPC, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cib * CPC, tid);
+        __syncthreads();
+        for (int row = 0; row < TX * TY; ++row) {
+            const int xl = row / TY, yl = row % TY;
+            frag_t a[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const char* ap = dyt + (row * TZW + 8 * lg + q) * VSD + (mb * 16 + 4 * p4) * 2;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, ap));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, ap + 4 * VSD));
+                const short8v rr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[mb] = __builtin_bit_cast(frag_t, rr);
+            }
+#pragma unroll
+            for (int k = 0; k < WTAPS; ++k) {
+                const int tap = wave + 4 * k;
+                if (tap < 27) {
+                    const int dx = tap / 9, dyy = (tap / 3) % 3, dz = tap % 3;
+                    const char* bp = halo + ((((xl + dx) * HY + yl + dyy) * HZ) + dz + 8 * lg + q) * G::VS + 4 * p4 * 2;
+#pragma unroll
+                    for (int nb = 0; nb < NBK; ++nb) {
+                        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, bp + nb * 32));
+                        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, bp + nb * 32 + 4 * G::VS));
+                        const short8v rr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const frag_t bf = __builtin_bit_cast(frag_t, rr);
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) acc[k][mb][nb] = mma(a[mb], bf, acc[k][mb][nb]);
+                    }
+                }
+            }
+        }
+    }
+    // partial [blockIdx.x][blockIdx.y][tap][16 MB][16 NBK]; D[co = 4 lg + e][ci = li]
+    constexpr int PB = 16 * MB * 16 * NBK;
+    float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 27 * PB;
+#pragma unroll
+    for (int k = 0; k < WTAPS; ++k) {
+        const int tap = wave + 4 * k;
+        if (tap < 27) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[tap * PB + (mb * 16 + 4 * lg + e) * (16 * NBK) + nb * 16 + li] = acc[k][mb][nb][e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- data movers
+// depth-to-space of the transposed convolution's GEMM output: cols [B Xi Yi Zi][8 C] with the 8 = (dx, dy, dz) -> out [B][2Xi][2Yi][2Zi][C]
+// (to_space = 1), or the inverse gather for the backward pass (to_space = 0).  16 bytes per thread step; C % 8 == 0.
+__global__ __launch_bounds__(CT) void d2s_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int Xi, int Yi, int Zi, int C,
+                                                 int to_space) {
+    const int cv = C / 8;
+    const int64_t total = (int64_t)B * Xi * Yi * Zi * 8 * cv;
+    for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < total; i += (int64_t)gridDim.x * CT) {
+        // i walks the SPACE tensor [b][xo][yo][zo][cv]
+        int64_t r = i;
+        const int c = (int)(r % cv);
+        r /= cv;
+        const int zo = (int)(r % (2 * Zi));
+        r /= 2 * Zi;
+        const int yo = (int)(r % (2 * Yi));
+        r /= 2 * Yi;
+        const int xo = (int)(r % (2 * Xi));
+        const int64_t b = r / (2 * Xi);
+        const int64_t vin = ((b * Xi + (xo >> 1)) * Yi + (yo >> 1)) * Zi + (zo >> 1);
+        const int64_t j = (vin * 8 + ((xo & 1) * 4 + (yo & 1) * 2 + (zo & 1))) * cv + c;
+        if (to_space)
+            reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[j];
+        else
+            reinterpret_cast<u32x4*>(dst)[j] = reinterpret_cast<const u32x4*>(src)[i];
+    }
+}
+
+// fp32 [V] -> bf16 [V][8] with channels 1..7 zero: the single-channel input volume as an 8-channel operand of the MFMA kernels
+__global__ __launch_bounds__(CT) void pad8_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t V) {
+    for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < V; i += (int64_t)gridDim.x * CT) {
+        bf16x8 o;
+        o[0] = (bf16)src[i];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) o[e] = (bf16)0.f;
+        reinterpret_cast<bf16x8*>(dst)[i] = o;
+    }
+}
+
+int conv_check(const char* name, const void* x, const void* w, const void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
+               int64_t Cout) {
+    UCF_CHECK_ARG(x && w && y, "%s: null pointer", name);
+    UCF_CHECK_ARG(B > 0 && X > 0 && Y > 0 && Z > 0, "%s: empty volume", name);
+    UCF_CHECK_ARG(B * X * Y * Z < (1ll << 31), "%s: more than 2^31 voxels", name);
+    UCF_CHECK_ARG(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0), "%s: Cin must be 8, 16 or a multiple of 32 (got %lld)", name, (long long)Cin);
+    UCF_CHECK_ARG(Cout > 0 && Cout % 16 == 0, "%s: Cout must be a multiple of 16 (got %lld)", name, (long long)Cout);
+    UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(w) && (((uintptr_t)y) & 7) == 0, "%s: operands must be 16-byte aligned", name);
+    return UCFVIT_OK;
+}
+
+template <int CPC, int NB, int TX, int TY>
+int launch_fwd(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, hipStream_t s) {
+    typedef CG<CPC> G;
+    g.tx = (g.X + TX - 1) / TX;
+    g.ty = (g.Y + TY - 1) / TY;
+    g.tz = (g.Z + 15) / 16;
+    const int64_t tiles = (int64_t)g.B * g.tx * g.ty * g.tz;
+    UCF_CHECK_ARG(tiles < (1ll << 31) && g.Cout / (16 * NB) < 65536, "ucfvit_conv3d_fwd: grid too large");
+    g.tiles = (int)tiles;
+    constexpr int SMEM = (TX + 2) * (TY + 2) * 18 * G::VS + G::NTS * 16 * NB * 64;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3_fwd_kernel<CPC, NB, TX, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3_fwd_kernel<CPC, NB, TX, TY>), dim3(g.tiles, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp, y, g);
+    UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
+    return UCFVIT_OK;
+}
+
+template <int CPC, int MB, int TX, int TY> struct WG {
+    static constexpr int NBK = CPC >= 16 ? CPC / 16 : 1;
+    static constexpr int PB = 16 * MB * 16 * NBK;
+    static constexpr int SMEM = TX * TY * TZW * 32 * MB + (TX + 2) * (TY + 2) * (TZW + 2) * CG<CPC>::VS + 64;
+};
+
+constexpr int64_t WGRAD_PART_FLOATS = 32ll << 20;      // cap of the partial-sum scratch (128 MiB)
+
+// geometry shared by the workspace query and the launch
+template <int CPC, int MB, int TX, int TY>
+void wgrad_plan(ConvGeo& g, int& n_wg, int& tiles_per_wg, int& gy, int64_t& n_out) {
+    g.tx = (g.X + TX - 1) / TX;
+    g.ty = (g.Y + TY - 1) / TY;
+    g.tz = (g.Z + TZW - 1) / TZW;
+    g.tiles = g.B * g.tx * g.ty * g.tz;
+    gy = (g.Cin / CPC) * (g.Cout / (16 * MB));
+    n_out = (int64_t)gy * 27 * WG<CPC, MB, TX, TY>::PB;
+    int64_t cap = WGRAD_PART_FLOATS / n_out;
+    if (cap < 1) cap = 1;
+    if (cap > 1024) cap = 1024;
+    n_wg = (int)(g.tiles < cap ? g.tiles : cap);
+    tiles_per_wg = (g.tiles + n_wg - 1) / n_wg;
+    n_wg = (g.tiles + tiles_per_wg - 1) / tiles_per_wg;
+}
+
+template <int CPC, int MB, int TX, int TY>
+int launch_wgrad(const bf16* x, const bf16* dy, float* dw, float* ws, ConvGeo g, hipStream_t s) {
+    int n_wg, tpw, gy;
+    int64_t n_out;
+    wgrad_plan<CPC, MB, TX, TY>(g, n_wg, tpw, gy, n_out);
+    constexpr int SMEM = WG<CPC, MB, TX, TY>::SMEM;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3_wgrad_kernel<CPC, MB, TX, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3_wgrad_kernel<CPC, MB, TX, TY>), dim3(n_wg, gy), dim3(CT), SMEM, s, x, dy, ws, g, tpw);
+    UCF_LAUNCH_CHECK("ucfvit_conv3d_wgrad");
+    return ucfvit_reduce_rows(ws, dw, n_wg, n_out, 0, s);
+}
+
+// which instantiation serves (Cin, Cout):  CPC = min(Cin, 32);  forward NB = largest of 4, 2, 1 dividing Cout / 16;  weight gradient MB = 2
+// when Cout % 32 == 0
+#define CONV_CPC_SWITCH(CIN, ...)              \
+    do {                                       \
+        if ((CIN) == 8) {                      \
+            constexpr int CPC_ = 8;            \
+            __VA_ARGS__                        \
+        } else if ((CIN) == 16) {              \
+            constexpr int CPC_ = 16;           \
+            __VA_ARGS__                        \
+        } else {                               \
+            constexpr int CPC_ = 32;           \
+            __VA_ARGS__                        \
+        }                                      \
+    } while (0)
+
+}  // namespace
+
+// x [B][X][Y][Z][Cin] bf16, w_packed [Cin/CPC][NTS][Cout][32] bf16 -> y [B][X][Y][Z][Cout] bf16
+extern "C" int ucfvit_conv3d_fwd(const void* x, const void* w_packed, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
+                                 int64_t Cout, void* stream) {
+    if (int rc = conv_check("ucfvit_conv3d_fwd", x, w_packed, y, B, X, Y, Z, Cin, Cout)) return rc;
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    const int nb16 = (int)(Cout / 16);
+    CONV_CPC_SWITCH(Cin, {
+        if (nb16 % 4 == 0) return launch_fwd<CPC_, 4, 2, 4>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, g, s);
+        if (nb16 % 2 == 0) return launch_fwd<CPC_, 2, 2, 8>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, g, s);
+        return launch_fwd<CPC_, 1, 2, 8>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, g, s);
+    });
+    return UCFVIT_OK;
+}
+
+// number of fp32 values of the packed weight gradient [Cin/CPC * Cout/(16 MB)][27][16 MB][16 NBK] and bytes of scratch for the partials
+extern "C" int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout) {
+    const int64_t cpc = Cin < 32 ? Cin : 32;
+    const int64_t nbk16 = cpc >= 16 ? cpc : 16;
+    return (Cin / cpc) * 27 * Cout * nbk16;
+}
+extern "C" int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout) {
+    if (!(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0)) || Cout <= 0 || Cout % 16) return 0;
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0};
+    int n_wg = 0, tpw = 0, gy = 0;
+    int64_t n_out = 0;
+    CONV_CPC_SWITCH(Cin, {
+        if (Cout % 32 == 0)
+            wgrad_plan<CPC_, 2, 2, 4>(g, n_wg, tpw, gy, n_out);
+        else
+            wgrad_plan<CPC_, 1, 2, 4>(g, n_wg, tpw, gy, n_out);
+    });
+    return (int64_t)n_wg * n_out * (int64_t)sizeof(float);
+}
+// x [..][Cin], dy [..][Cout] bf16 -> dw_packed fp32 (layout above; UCF_VIT/_hip/conv.py:unpack_conv3_wgrad turns it into [Cout][Cin][3][3][3])
+extern "C" int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y,
+                                   int64_t Z, int64_t Cin, int64_t Cout, void* stream) {
+    if (int rc = conv_check("ucfvit_conv3d_wgrad", x, dy, dw_packed, B, X, Y, Z, Cin, Cout)) return rc;
+    UCF_CHECK_ARG(workspace, "ucfvit_conv3d_wgrad: null workspace");
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    CONV_CPC_SWITCH(Cin, {
+        if (Cout % 32 == 0) return launch_wgrad<CPC_, 2, 2, 4>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
+        return launch_wgrad<CPC_, 1, 2, 4>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
+    });
+    return UCFVIT_OK;
+}
+
+// to_space = 1: cols [B Xi Yi Zi][8 C] -> out [B][2Xi][2Yi][2Zi][C];  to_space = 0: the inverse.  bf16, C % 8 == 0.
+extern "C" int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int to_space,
+                                      void* stream) {
+    UCF_CHECK_ARG(src && dst && B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && C > 0 && C % 8 == 0, "ucfvit_depth_to_space2: bad arguments");
+    UCF_CHECK_ARG(ucf_is_aligned16(src) && ucf_is_aligned16(dst), "ucfvit_depth_to_space2: operands must be 16-byte aligned");
+    const int64_t total = B * Xi * Yi * Zi * C;       // 16-byte pieces: 8 sub-voxels x C / 8
+    int64_t blocks = (total + CT - 1) / CT;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(d2s_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, (int)B, (int)Xi,
+                       (int)Yi, (int)Zi, (int)C, to_space);
+    UCF_LAUNCH_CHECK("ucfvit_depth_to_space2");
+    return UCFVIT_OK;
+}
+
+extern "C" int ucfvit_pad_channels8(const float* src, void* dst, int64_t V, void* stream) {
+    UCF_CHECK_ARG(src && dst && V > 0 && ucf_is_aligned16(dst), "ucfvit_pad_channels8: bad arguments");
+    int64_t blocks = (V + CT - 1) / CT;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pad8_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, src, (bf16*)dst, V);
+    UCF_LAUNCH_CHECK("ucfvit_pad_channels8");
+    return UCFVIT_OK;
+}

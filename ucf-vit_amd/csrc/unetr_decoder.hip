@@ -177,10 +177,10 @@ constexpr int DSTAT = 3 * MAXC + 1;       // per batch element: I[8], P[8], C[8]
 
 template <typename T>
 __global__ __launch_bounds__(NT) void dice_partial(const T* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ part,
-                                                   int n, int64_t S, int chunks) {
+                                                   int n, int64_t S, int chunks, int64_t sb, int64_t sc, int64_t ss) {
     __shared__ float red[NT / 64];
     const int64_t b = blockIdx.y;
-    const T* lb = logits + b * n * S;
+    const T* lb = logits + b * sb;
     const int64_t* yb = labels + b * S;
     const int64_t lo = (int64_t)blockIdx.x * CHUNK, hi = min(S, lo + CHUNK);
     float I[MAXC], P[MAXC], Cn[MAXC], ce = 0.f;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NT) void dice_partial(const T* __restrict__ logits,
         float z[MAXC], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            z[c] = c < n ? ld(lb, c * S + i) : -INFINITY;
+            z[c] = c < n ? ld(lb, c * sc + i * ss) : -INFINITY;
             mx = fmaxf(mx, z[c]);
         }
         float den = 0.f;
@@ -251,10 +251,11 @@ __global__ __launch_bounds__(64) void dice_final(const float* __restrict__ part,
 //                     dz_c = p_c (g_c - sum_k g_k p_k) + (p_c - onehot_c) / (B S)
 template <typename T>
 __global__ __launch_bounds__(NT) void dice_bwd(const T* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ stats,
-                                               T* __restrict__ dlogits, int B, int n, int64_t S, float s_nr, float s_dr, float gscale) {
+                                               T* __restrict__ dlogits, int B, int n, int64_t S, float s_nr, float s_dr, float gscale,
+                                               int64_t sb, int64_t sc, int64_t ss) {
     const int64_t b = blockIdx.y;
-    const T* lb = logits + b * n * S;
-    T* db = dlogits + b * n * S;
+    const T* lb = logits + b * sb;
+    T* db = dlogits + b * sb;
     const int64_t* yb = labels + b * S;
     float a[MAXC], bq[MAXC];                   // g_c = a_c onehot_c + bq_c p_c
     const float wb = 1.f / ((float)B * (float)n), wce = 1.f / ((float)B * (float)S);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(NT) void dice_bwd(const T* __restrict__ logits, con
         float z[MAXC], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
-            z[c] = c < n ? ld(lb, c * S + i) : -INFINITY;
+            z[c] = c < n ? ld(lb, c * sc + i * ss) : -INFINITY;
             mx = fmaxf(mx, z[c]);
         }
         float den = 0.f;
@@ -288,8 +289,188 @@ __global__ __launch_bounds__(NT) void dice_bwd(const T* __restrict__ logits, con
         }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
-            if (c < n) db[c * S + i] = from_f32<T>(gscale * (z[c] * (g[c] - dot) + (z[c] - (c == lab ? 1.f : 0.f)) * wce));
+            if (c < n) db[c * sc + i * ss] = from_f32<T>(gscale * (z[c] * (g[c] - dot) + (z[c] - (c == lab ? 1.f : 0.f)) * wce));
     }
+}
+
+// ---- channels-last instance norm: x [B][S][C] bf16 (the layout of csrc/conv3d.hip), C = 8 * (a power of two <= 32 ... 256) -----------------
+// A thread always meets the same 8 channels (its 16-byte vector index mod C/8 is fixed because both the workgroup size and the chunk
+// size are multiples of C/8), so the per-channel sums live in registers and are folded once per workgroup through LDS.
+constexpr int CLV = 4096;          // 16-byte vectors per workgroup in the reduction passes
+
+__device__ __forceinline__ void cl_fold(const float (&s1)[8], const float (&s2)[8], float (*red)[17], float* out, int C, int cv) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[threadIdx.x][e] = s1[e];
+        red[threadIdx.x][8 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * C; o += NT) {
+        const int k = o / C, c = o % C, cg = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int t = cg; t < NT; t += cv) s += red[t][k * 8 + e];
+        out[o] = s;                                                 // [2][C]
+    }
+}
+
+__global__ __launch_bounds__(NT) void incl_stats_partial(const bf16* __restrict__ x, float* __restrict__ part, int64_t S, int C, int chunks) {
+    __shared__ float red[NT][17];
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3;
+    const int64_t nvec = S * cv, vlo = (int64_t)blockIdx.x * CLV, vhi = min(nvec, vlo + CLV);
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    const bf16x8 sh = xb[threadIdx.x % cv];                         // shift = the first voxel (keeps E[x^2] - mean^2 well conditioned)
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (int64_t i = vlo + threadIdx.x; i < vhi; i += NT) {
+        const bf16x8 v = xb[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (float)v[e] - (float)sh[e];
+            s1[e] += d;
+            s2[e] += d * d;
+        }
+    }
+    cl_fold(s1, s2, red, part + (b * chunks + blockIdx.x) * 2 * C, C, cv);
+}
+__global__ __launch_bounds__(64) void incl_stats_final(const bf16* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int64_t S, int C, int chunks, float eps) {
+    const int64_t b = blockIdx.x / C;
+    const int c = blockIdx.x % C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+        s1 += part[(b * chunks + ch) * 2 * C + c];
+        s2 += part[(b * chunks + ch) * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double m = s1 / (double)S;
+        const double var = fmax(s2 / (double)S - m * m, 0.0);
+        mean[blockIdx.x] = (float)(m + (double)(float)x[b * S * C + c]);
+        rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+template <bool RES>
+__global__ __launch_bounds__(NT) void incl_apply(const bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                 const bf16* __restrict__ res, bf16* __restrict__ y, int64_t S, int C, float slope) {
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3, cg = threadIdx.x % cv;
+    float m[8], r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m[e] = mean[b * C + cg * 8 + e];
+        r[e] = rstd[b * C + cg * 8 + e];
+    }
+    const int64_t nvec = S * cv;
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    const bf16x8* rb = reinterpret_cast<const bf16x8*>(res + b * S * C);
+    bf16x8* yb = reinterpret_cast<bf16x8*>(y + b * S * C);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
+        const bf16x8 xv = xb[i];
+        bf16x8 rv, o;
+        if (RES) rv = rb[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = ((float)xv[e] - m[e]) * r[e];
+            if (RES) v += (float)rv[e];
+            o[e] = (bf16)(v >= 0.f ? v : v * slope);
+        }
+        yb[i] = o;
+    }
+}
+__global__ __launch_bounds__(NT) void incl_bwd_partial(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ part,
+                                                       int64_t S, int C, int chunks, float slope) {
+    __shared__ float red[NT][17];
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3, cg = threadIdx.x % cv;
+    float m[8], r[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m[e] = mean[b * C + cg * 8 + e];
+        r[e] = rstd[b * C + cg * 8 + e];
+        s1[e] = s2[e] = 0.f;
+    }
+    const int64_t nvec = S * cv, vlo = (int64_t)blockIdx.x * CLV, vhi = min(nvec, vlo + CLV);
+    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy + b * S * C);
+    const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    for (int64_t i = vlo + threadIdx.x; i < vhi; i += NT) {
+        const bf16x8 gv = gb[i], yv = yb[i], xv = xb[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = (float)gv[e] * ((float)yv[e] > 0.f ? 1.f : slope);
+            s1[e] += g;
+            s2[e] += g * ((float)xv[e] - m[e]) * r[e];
+        }
+    }
+    cl_fold(s1, s2, red, part + (b * chunks + blockIdx.x) * 2 * C, C, cv);
+}
+__global__ __launch_bounds__(64) void incl_bwd_final(const float* __restrict__ part, float* __restrict__ m1, float* __restrict__ m2, int64_t S,
+                                                     int C, int chunks) {
+    const int64_t b = blockIdx.x / C;
+    const int c = blockIdx.x % C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+        s1 += part[(b * chunks + ch) * 2 * C + c];
+        s2 += part[(b * chunks + ch) * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        m1[blockIdx.x] = (float)(s1 / (double)S);
+        m2[blockIdx.x] = (float)(s2 / (double)S);
+    }
+}
+template <bool RES>
+__global__ __launch_bounds__(NT) void incl_bwd_apply(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m1,
+                                                     const float* __restrict__ m2, bf16* __restrict__ dx, bf16* __restrict__ dres, int64_t S, int C,
+                                                     float slope) {
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3, cg = threadIdx.x % cv;
+    float m[8], r[8], a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m[e] = mean[b * C + cg * 8 + e];
+        r[e] = rstd[b * C + cg * 8 + e];
+        a1[e] = m1[b * C + cg * 8 + e];
+        a2[e] = m2[b * C + cg * 8 + e];
+    }
+    const int64_t nvec = S * cv;
+    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy + b * S * C);
+    const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    bf16x8* dxb = reinterpret_cast<bf16x8*>(dx + b * S * C);
+    bf16x8* drb = reinterpret_cast<bf16x8*>(dres + b * S * C);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
+        const bf16x8 gv = gb[i], yv = yb[i], xv = xb[i];
+        bf16x8 ox, orr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dn = (float)gv[e] * ((float)yv[e] > 0.f ? 1.f : slope);
+            const float n = ((float)xv[e] - m[e]) * r[e];
+            ox[e] = (bf16)(r[e] * (dn - a1[e] - n * a2[e]));
+            if (RES) orr[e] = (bf16)dn;
+        }
+        dxb[i] = ox;
+        if (RES) drb[i] = orr;
+    }
+}
+int cl_chunks_of(int64_t S, int64_t C) { return (int)((S * (C / 8) + CLV - 1) / CLV); }
+unsigned cl_apply_grid(int64_t S, int64_t C, int64_t B) {
+    int64_t g = (S * (C / 8) + NT - 1) / NT;
+    const int64_t cap = (4096 + B - 1) / B;
+    if (g > cap) g = cap;
+    return (unsigned)(g < 1 ? 1 : g);
 }
 
 int chunks_of(int64_t S) { return (int)((S + CHUNK - 1) / CHUNK); }
@@ -370,24 +551,84 @@ extern "C" int ucfvit_instnorm_bwd(const void* dy, const void* y, const void* x,
 
 extern "C" int64_t ucfvit_dice_ce_workspace(int64_t B, int64_t S) { return (B * chunks_of(S) * DSTAT + B * DSTAT) * (int64_t)sizeof(float); }
 
-extern "C" int ucfvit_dice_ce(const void* logits, const int64_t* labels, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S,
-                              float smooth_nr, float smooth_dr, float grad_scale, void* workspace, int dtype, void* stream) {
+// logits element (b, class c, voxel i) at logits[b stride_b + c stride_c + i stride_s] (dlogits alike): N C (D) H W is (n S, S, 1), a
+// channels-last tensor with row stride ld is (S ld, 1, ld)
+extern "C" int ucfvit_dice_ce_strided(const void* logits, const int64_t* labels, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S,
+                                      int64_t stride_b, int64_t stride_c, int64_t stride_s, float smooth_nr, float smooth_dr, float grad_scale,
+                                      void* workspace, int dtype, void* stream) {
     UCF_CHECK_ARG(logits && labels && loss && workspace, "ucfvit_dice_ce: null pointer");
     UCF_CHECK_ARG(B > 0 && B < 65536 && S > 0 && n >= 2 && n <= MAXC, "ucfvit_dice_ce: need 2 <= classes <= %d, B in 1..65535", MAXC);
     UCF_CHECK_ARG(dtype == UCFVIT_F32 || dtype == UCFVIT_BF16, "ucfvit_dice_ce: bad dtype %d", dtype);
+    UCF_CHECK_ARG(stride_b > 0 && stride_c > 0 && stride_s > 0, "ucfvit_dice_ce: strides must be positive");
     hipStream_t s = (hipStream_t)stream;
     const int ch = chunks_of(S);
     float* part = (float*)workspace;
     float* stats = part + B * ch * DSTAT;
     IN_DISPATCH(T, {
-        hipLaunchKernelGGL((dice_partial<T>), dim3(ch, (unsigned)B), dim3(NT), 0, s, (const T*)logits, labels, part, (int)n, S, ch);
+        hipLaunchKernelGGL((dice_partial<T>), dim3(ch, (unsigned)B), dim3(NT), 0, s, (const T*)logits, labels, part, (int)n, S, ch, stride_b,
+                           stride_c, stride_s);
         hipLaunchKernelGGL(dice_final, dim3(1), dim3(64), 0, s, part, stats, loss, (int)B, (int)n, S, ch, smooth_nr, smooth_dr);
         if (dlogits) {
             const dim3 g(apply_grid(S * 4, B), (unsigned)B);
             hipLaunchKernelGGL((dice_bwd<T>), g, dim3(NT), 0, s, (const T*)logits, labels, stats, (T*)dlogits, (int)B, (int)n, S, smooth_nr,
-                               smooth_dr, grad_scale);
+                               smooth_dr, grad_scale, stride_b, stride_c, stride_s);
         }
     });
     UCF_LAUNCH_CHECK("ucfvit_dice_ce");
+    return UCFVIT_OK;
+}
+
+extern "C" int ucfvit_dice_ce(const void* logits, const int64_t* labels, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S,
+                              float smooth_nr, float smooth_dr, float grad_scale, void* workspace, int dtype, void* stream) {
+    return ucfvit_dice_ce_strided(logits, labels, loss, dlogits, B, n, S, n * S, S, 1, smooth_nr, smooth_dr, grad_scale, workspace, dtype, stream);
+}
+
+// ---- channels-last instance norm entry points: x, res, y [B][S][C] bf16; mean, rstd [B][C] fp32 ----------------------------------------------
+static int incl_check(const char* name, const void* x, int64_t B, int64_t S, int64_t C) {
+    UCF_CHECK_ARG(x && B > 0 && B < 65536 && S > 0, "%s: need B in 1..65535 and S > 0", name);
+    UCF_CHECK_ARG(C >= 8 && C <= 2048 && (C & (C - 1)) == 0, "%s: C must be a power of two in 8..2048 (got %lld)", name, (long long)C);
+    UCF_CHECK_ARG(ucf_is_aligned16(x), "%s: operands must be 16-byte aligned", name);
+    return UCFVIT_OK;
+}
+extern "C" int64_t ucfvit_instnorm_cl_workspace(int64_t B, int64_t S, int64_t C) {
+    return (B * cl_chunks_of(S, C) * 2 * C + 2 * B * C) * (int64_t)sizeof(float);
+}
+extern "C" int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, float* mean, float* rstd, int64_t B, int64_t S, int64_t C,
+                                      float eps, float slope, void* workspace, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_fwd", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(y && mean && rstd && workspace, "ucfvit_instnorm_cl_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = cl_chunks_of(S, C);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(incl_stats_partial, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)x, part, S, (int)C, ch);
+    hipLaunchKernelGGL(incl_stats_final, dim3((unsigned)(B * C)), dim3(64), 0, s, (const bf16*)x, part, mean, rstd, S, (int)C, ch, eps);
+    const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+    if (res)
+        hipLaunchKernelGGL((incl_apply<true>), g, dim3(NT), 0, s, (const bf16*)x, mean, rstd, (const bf16*)res, (bf16*)y, S, (int)C, slope);
+    else
+        hipLaunchKernelGGL((incl_apply<false>), g, dim3(NT), 0, s, (const bf16*)x, mean, rstd, (const bf16*)x, (bf16*)y, S, (int)C, slope);
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_fwd");
+    return UCFVIT_OK;
+}
+extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres,
+                                      int64_t B, int64_t S, int64_t C, float slope, void* workspace, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_bwd", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(dy && y && mean && rstd && dx && workspace, "ucfvit_instnorm_cl_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = cl_chunks_of(S, C);
+    float* part = (float*)workspace;
+    float* m1 = part + B * ch * 2 * C;
+    float* m2 = m1 + B * C;
+    hipLaunchKernelGGL(incl_bwd_partial, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, part,
+                       S, (int)C, ch, slope);
+    hipLaunchKernelGGL(incl_bwd_final, dim3((unsigned)(B * C)), dim3(64), 0, s, part, m1, m2, S, (int)C, ch);
+    const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+    if (dres)
+        hipLaunchKernelGGL((incl_bwd_apply<true>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2,
+                           (bf16*)dx, (bf16*)dres, S, (int)C, slope);
+    else
+        hipLaunchKernelGGL((incl_bwd_apply<false>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2,
+                           (bf16*)dx, (bf16*)dx, S, (int)C, slope);
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd");
     return UCFVIT_OK;
 }
