@@ -368,7 +368,8 @@ int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const f
  *   workspace: ucfvit_conv3d_wgrad_workspace bytes (per-workgroup partials, folded in a fixed order: deterministic).
  * ucfvit_depth_to_space2: the transposed convolution is the GEMM x[V][Cin] * w[Cin][8 Cout] followed by this shuffle of
  *   cols [B Xi Yi Zi][(dx, dy, dz)][C] into out [B][2 Xi][2 Yi][2 Zi][C] (to_space = 1) — or its inverse for the backward pass (0).
- * ucfvit_pad_channels8: fp32 [V] -> bf16 [V][8] (channels 1..7 zero): the one-channel input volume as an operand of the kernels above.
+ * ucfvit_pad_channels8: fp32 N C D H W input [B][C][S] with C <= 8 -> bf16 channels-last [B][S][8] (channels C..7 zero): the input volume as
+ *   an operand of the kernels above.
  * ------------------------------------------------------------------------------------------------------ */
 int ucfvit_conv3d_fwd(const void* x, const void* w_packed, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout,
                       void* stream);
@@ -377,7 +378,7 @@ int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z
 int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y, int64_t Z,
                         int64_t Cin, int64_t Cout, void* stream);
 int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int to_space, void* stream);
-int ucfvit_pad_channels8(const float* src, void* dst, int64_t V, void* stream);
+int ucfvit_pad_channels8(const float* src, void* dst, int64_t B, int64_t C, int64_t S, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,8 +90,11 @@ def test_conv3x3x3_single_channel_input_through_the_padded_operand():
     g = torch.Generator().manual_seed(3)
     vol = torch.randn(2, 6, 9, 20, generator=g).cuda()
     w = (torch.randn(16, 1, 3, 3, 3, generator=g) * 0.2).cuda().requires_grad_(True)
-    x8 = ops.pad_channels8(vol)
+    x8 = ops.pad_channels8(vol[:, None].contiguous())
     assert x8.shape == (2, 6, 9, 20, 8) and torch.equal(x8[..., 0].float(), vol.bfloat16().float()) and x8[..., 1:].abs().max() == 0
+    v3 = torch.randn(2, 3, 4, 5, 6, generator=g).cuda()
+    x3 = ops.pad_channels8(v3)
+    assert torch.equal(x3[..., :3].float(), v3.permute(0, 2, 3, 4, 1).bfloat16().float()) and x3[..., 3:].abs().max() == 0
     y = conv.conv3x3x3(x8, w)
     dy = torch.randn(y.shape, generator=g).bfloat16().cuda()
     y.backward(dy)

@@ -782,8 +782,11 @@ class DiceCEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, labels, smooth_nr, smooth_dr):
-        lg = logits if logits.is_contiguous() else logits.contiguous()
         lb = labels if labels.is_contiguous() else labels.contiguous()
+        if logits.is_contiguous() or _is_channels_last_rows(logits):       # the HIP decoder's logits: read in place, no N C D H W copy
+            lg = logits
+        else:
+            lg = logits.contiguous()
         loss, dl = ops.dice_ce(lg, lb, smooth_nr, smooth_dr, 1.0, want_grad=True)
         ctx.save_for_backward(dl)
         return loss
@@ -791,7 +794,23 @@ class DiceCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g.to(dl.dtype), None, None, None
+        if dl.is_contiguous():
+            return dl * g.to(dl.dtype), None, None, None
+        flat = dl.as_strided((dl.shape[0] * dl.stride(0),), (1,))           # the padded channels-last buffer behind the view
+        return (flat * g.to(dl.dtype)).as_strided(dl.shape, dl.stride()), None, None, None
+
+
+def _is_channels_last_rows(t):
+    """[B, n, *spatial] view over a dense [B, *spatial, ld >= n] buffer"""
+    if t.dim() < 3 or t.stride(1) != 1 or t.storage_offset() != 0:
+        return False
+    ld = t.stride(-1)
+    exp = ld
+    for d in range(t.dim() - 1, 1, -1):
+        if t.stride(d) != exp:
+            return False
+        exp *= t.shape[d]
+    return ld >= t.shape[1] and t.stride(0) == exp
 
 
 # ---------------------------------------------------------------------------------------------- public helpers

@@ -85,7 +85,7 @@ SIGNATURES = {
     "ucfvit_conv3d_wgrad_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64]),
     "ucfvit_conv3d_wgrad": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P]),
     "ucfvit_depth_to_space2": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
-    "ucfvit_pad_channels8": (c_int, [_P, _P, _I64, _P]),
+    "ucfvit_pad_channels8": (c_int, [_P, _P, _I64, _I64, _I64, _P]),
     "ucfvit_cross_entropy": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P]),
     "ucfvit_mae_mask": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "ucfvit_gather_rows": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),

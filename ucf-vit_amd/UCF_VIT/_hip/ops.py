@@ -663,13 +663,14 @@ def space_to_depth2(y):
 
 
 def pad_channels8(vol):
-    """fp32 [B, X, Y, Z] -> bf16 [B, X, Y, Z, 8], channel 0 = the volume, channels 1..7 zero"""
+    """fp32 [B, C, X, Y, Z] with C <= 8 -> channels-last bf16 [B, X, Y, Z, 8] (channels C..7 zero)"""
     L = _l.load()
     _chk(vol, "pad_channels8.vol")
-    if vol.dtype != torch.float32 or vol.dim() != 4:
-        raise TypeError("pad_channels8: expected an fp32 [B, X, Y, Z] volume")
-    out = torch.empty(tuple(vol.shape) + (8,), dtype=torch.bfloat16, device=vol.device)
-    _l.check(L.ucfvit_pad_channels8(vol.data_ptr(), out.data_ptr(), vol.numel(), _stream()), "ucfvit_pad_channels8")
+    if vol.dtype != torch.float32 or vol.dim() != 5 or vol.shape[1] > 8:
+        raise TypeError("pad_channels8: expected an fp32 [B, C <= 8, X, Y, Z] volume")
+    B, C = vol.shape[0], vol.shape[1]
+    out = torch.empty((B,) + tuple(vol.shape[2:]) + (8,), dtype=torch.bfloat16, device=vol.device)
+    _l.check(L.ucfvit_pad_channels8(vol.data_ptr(), out.data_ptr(), B, C, vol.numel() // (B * C), _stream()), "ucfvit_pad_channels8")
     return out
 
 

@@ -17,6 +17,8 @@ except ImportError:  # pragma: no cover
     from typing_extensions import Literal
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -524,9 +526,38 @@ class UNETR(VIT):
     def forward_head(self, x, intermediates, enc1):
         return self.unetr_head(self.pool(x), intermediates, enc1)
 
+    def hip_decoder(self):
+        """True when the convolutional decoder runs on the HIP kernels end to end (unetr_blocks.hip_decoder_supported); UCFVIT_UNETR_DECODER=torch
+        forces the torch/MIOpen convolutions (the A/B of tests/test_unetr_decoder_model.py)"""
+        from .unetr_blocks import hip_decoder_supported
+        if os.environ.get("UCFVIT_UNETR_DECODER", "hip") == "torch" or self.linear_decoder or not self.skip_connection:
+            return False
+        full = all(self.feat_size[i] * 16 == self.img_size[i] for i in range(len(self.feat_size)))
+        return full and hip_decoder_supported(2 if self.twoD else 3, self.in_chans, self.embed_dim, self.feature_size)
+
+    def _tokens_cl(self, t):
+        """token matrix [B, N, D] -> channels-last feature map [B, *feat_size, D] in bf16: a view, no permute (the decoder kernels read a
+        voxel's channels contiguously, which is what a token row is)"""
+        return t.to(torch.bfloat16).reshape(t.size(0), *self.feat_size, self.embed_dim)
+
+    def _unetr_head_cl(self, x, intermediates, enc1):
+        n = len(intermediates)
+        dec3 = self.decoder5.forward_cl(self._tokens_cl(x), self.encoder4.forward_cl(self._tokens_cl(intermediates[n - 1])))
+        dec2 = self.decoder4.forward_cl(dec3, self.encoder3.forward_cl(self._tokens_cl(intermediates[n - 2])))
+        dec1 = self.decoder3.forward_cl(dec2, self.encoder2.forward_cl(self._tokens_cl(intermediates[n - 3])))
+        logits = self.out.forward_cl(self.decoder2.forward_cl(dec1, enc1))            # [B, X, Y, Z, classes] fp32
+        return logits.permute(0, 4, 1, 2, 3)                                          # the reference's [B, classes, X, Y, Z] as a view
+
     def forward(self, x, variables, seq_ps=None, x_seq=None):
         tokens_in = x_seq if self.adaptive_patching else x
         if self.skip_connection:
+            if self.hip_decoder():
+                if not x.is_cuda:
+                    raise RuntimeError("UNETR: the convolutional decoder runs on the MI355X only; there is no CPU path")
+                from UCF_VIT._hip import ops as _ops
+                enc1 = self.encoder1.forward_cl(_ops.pad_channels8(x.float().contiguous()))
+                feats, intermediates = self.forward_intermediates(tokens_in, variables, seq_ps, indices=self.skip_indices)
+                return self._unetr_head_cl(self.pool(feats), intermediates, enc1)
             enc1 = self.encoder1(x)
             feats, intermediates = self.forward_intermediates(tokens_in, variables, seq_ps, indices=self.skip_indices)
             return self.forward_head(feats, intermediates, enc1)

@@ -2,13 +2,20 @@
 1x1 output conv).  In the reference these come from the un-vendored dependency monai>=1.4.0 (UnetrBasicBlock, UnetrPrUpBlock,
 UnetrUpBlock, UnetOutBlock; src/UCF_VIT/simple/arch.py:33-34,808-940): the classes below restate that published block
 structure and its state_dict naming so checkpoints line up.  PARITY UNPINNED: monai is not installed in the build container
-and the reference ships no fixtures for it.  Round 2 (partial): the instance norms with the
-LeakyReLU / residual add that follow them are fused HIP kernels (csrc/unetr_decoder.hip, two HBM passes each way instead of torch's chain
-of element-wise kernels), and the Dice + CE loss is one; the 3x3(x3) and transposed convolutions themselves still run on torch/MIOpen.
+and the reference ships no fixtures for it.
+
+Two execution paths over the SAME parameters (nn.Conv3d / nn.ConvTranspose3d modules are kept as the parameter containers):
+  forward_cl(...)  the 3-D decoder on the HIP kernels end to end: channels-last bf16 activations [B, X, Y, Z, C],
+                   3x3x3 convolutions as implicit GEMMs on MFMA, transposed convolutions as GEMM + depth-to-space, instance norm + LeakyReLU
+                   (+ residual) fused, csrc/conv3d.hip + csrc/unetr_decoder.hip through UCF_VIT/_hip/conv.py.  UNETR uses it whenever
+                   hip_decoder_supported() holds (3-D, kernel 3 / stride 1 / upsample 2, channel counts the kernels tile).
+  forward(...)     N C (D) H W tensors: convolutions on torch/MIOpen with the fused HIP instance-norm kernels between them — the 2-D
+                   models and unusual channel counts.
 """
 import torch
 import torch.nn as nn
 
+from UCF_VIT._hip import conv as HC
 from UCF_VIT._hip import functional as HF
 
 
@@ -47,6 +54,14 @@ class UnetResBlock(nn.Module):
         residual = HF.instnorm_act(self.conv3(inp), None, self.norm3.eps, 1.0) if self.downsample else inp
         return HF.instnorm_act(out, residual, self.norm2.eps, ns)
 
+    def forward_cl(self, inp):
+        """inp channels-last bf16 [B, X, Y, Z, Cin] -> [B, X, Y, Z, Cout]"""
+        ns = self.lrelu.negative_slope
+        out = HC.instnorm_act_cl(HC.conv3x3x3(inp, self.conv1.conv.weight), None, self.norm1.eps, ns)
+        out = HC.conv3x3x3(out, self.conv2.conv.weight)
+        residual = HC.instnorm_act_cl(HC.conv1x1x1(inp, self.conv3.conv.weight), None, self.norm3.eps, 1.0) if self.downsample else inp
+        return HC.instnorm_act_cl(out, residual, self.norm2.eps, ns)
+
 
 class UnetrBasicBlock(nn.Module):
     def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, res_block=False):
@@ -55,6 +70,9 @@ class UnetrBasicBlock(nn.Module):
 
     def forward(self, inp):
         return self.layer(inp.float())
+
+    def forward_cl(self, inp):
+        return self.layer.forward_cl(inp)
 
 
 class UnetrPrUpBlock(nn.Module):
@@ -74,6 +92,12 @@ class UnetrPrUpBlock(nn.Module):
             x = blk(x)
         return x
 
+    def forward_cl(self, x):
+        x = HC.tconv2x2x2(x, self.transp_conv_init.conv.weight)
+        for blk in self.blocks:
+            x = blk[1].forward_cl(HC.tconv2x2x2(x, blk[0].conv.weight))
+        return x
+
 
 class UnetrUpBlock(nn.Module):
     def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, upsample_kernel_size, norm_name, res_block=False):
@@ -86,6 +110,10 @@ class UnetrUpBlock(nn.Module):
         out = self.transp_conv(inp.float())
         return self.conv_block(torch.cat((out, skip), dim=1))
 
+    def forward_cl(self, inp, skip):
+        out = HC.tconv2x2x2(inp, self.transp_conv.conv.weight)
+        return self.conv_block.forward_cl(torch.cat((out, skip), dim=-1))
+
 
 class UnetOutBlock(nn.Module):
     def __init__(self, spatial_dims, in_channels, out_channels):
@@ -94,3 +122,16 @@ class UnetOutBlock(nn.Module):
 
     def forward(self, inp):
         return self.conv(inp)
+
+    def forward_cl(self, inp):
+        """-> fp32 logits [B, X, Y, Z, n]: a view of a buffer whose voxel rows are padded to 8 columns (ops.dice_ce reads it in place)"""
+        return HC.conv1x1x1(inp, self.conv.conv.weight, self.conv.conv.bias, out_fp32=True)
+
+
+def hip_decoder_supported(spatial_dims, in_chans, embed_dim, feature_size, kernel_size=3, upsample_kernel_size=2):
+    """can the whole skip-connection decoder run on csrc/conv3d.hip?  3-D, 3x3x3 / 2x2x2 kernels, an input of <= 8 channels (zero-padded to the
+    8-channel MFMA operand), feature_size a multiple of 16 whose multiples (x2, x4, x8, and the concatenations x2 .. x16) the kernels tile
+    (16, or any multiple of 32), embed_dim a multiple of 8"""
+    fs = feature_size
+    return (spatial_dims == 3 and kernel_size == 3 and upsample_kernel_size == 2 and 1 <= in_chans <= 8 and embed_dim % 8 == 0
+            and fs % 16 == 0 and (fs == 16 or fs % 32 == 0) and (fs & (fs - 1)) == 0)

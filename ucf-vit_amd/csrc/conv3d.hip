@@ -264,13 +264,14 @@ __global__ __launch_bounds__(CT) void d2s_kernel(const bf16* __restrict__ src, b
     }
 }
 
-// fp32 [V] -> bf16 [V][8] with channels 1..7 zero: the single-channel input volume as an 8-channel operand of the MFMA kernels
-__global__ __launch_bounds__(CT) void pad8_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t V) {
+// fp32 [B][C][S] (C <= 8) -> bf16 [B][S][8], channels C..7 zero: the input volume as an 8-channel operand of the MFMA kernels
+__global__ __launch_bounds__(CT) void pad8_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t B, int C, int64_t S) {
+    const int64_t V = B * S;
     for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < V; i += (int64_t)gridDim.x * CT) {
+        const int64_t b = i / S, v = i % S;
         bf16x8 o;
-        o[0] = (bf16)src[i];
 #pragma unroll
-        for (int e = 1; e < 8; ++e) o[e] = (bf16)0.f;
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(e < C ? src[(b * C + e) * S + v] : 0.f);
         reinterpret_cast<bf16x8*>(dst)[i] = o;
     }
 }
@@ -429,11 +430,11 @@ extern "C" int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int
     return UCFVIT_OK;
 }
 
-extern "C" int ucfvit_pad_channels8(const float* src, void* dst, int64_t V, void* stream) {
-    UCF_CHECK_ARG(src && dst && V > 0 && ucf_is_aligned16(dst), "ucfvit_pad_channels8: bad arguments");
-    int64_t blocks = (V + CT - 1) / CT;
+extern "C" int ucfvit_pad_channels8(const float* src, void* dst, int64_t B, int64_t C, int64_t S, void* stream) {
+    UCF_CHECK_ARG(src && dst && B > 0 && S > 0 && C >= 1 && C <= 8 && ucf_is_aligned16(dst), "ucfvit_pad_channels8: need 1 <= C <= 8");
+    int64_t blocks = (B * S + CT - 1) / CT;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(pad8_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, src, (bf16*)dst, V);
+    hipLaunchKernelGGL(pad8_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, src, (bf16*)dst, B, (int)C, S);
     UCF_LAUNCH_CHECK("ucfvit_pad_channels8");
     return UCFVIT_OK;
 }
