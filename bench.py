@@ -16,6 +16,9 @@ workloads (BASELINE.json configs):
   unetr_enc_512x512x128  configs[4], encoder: 512x512x128 volumes, p 16 -> 8192 tokens, D 768 / 12 / 12, taps after blocks 3, 6, 9
                          (simple/arch.py:995-1086); synthetic quadratic objective on the taps + features (the conv decoder and the
                          Dice/CE loss are SURVEY §8f row 2, outside this figure: BASELINE.md §4 "conv decoder excluded")
+  unetr_512x512x128      configs[4], whole model: the encoder above + the skip-connection convolutional decoder (UnetrBasicBlock / UnetrPrUpBlock /
+                         UnetrUpBlock, feature_size 16, simple/arch.py:808-940) on the HIP convolution kernels + Dice/CE loss
+                         (train_unetr_simple.py:38) on 4 classes
 roofline: the dominant kernel family of the workload — the bf16 MFMA GEMM (gemm3_kernel, csrc/gemm2.hip) for the 224^2 workloads, the
           streaming attention kernels (csrc/attention.hip) for the 8192-token encoder; `achieved` = algorithmic FLOPs of that family's
           launches in the timed region / their HIP-event-measured durations (events recorded on the launch stream).
@@ -48,6 +51,7 @@ WORKLOADS = {
                             dec_dim=512, dec_depth=8, dec_heads=16),
     # per-GPU batch 2 = the reference's basic_ct batch size (configs/basic_ct/unetr/base_config.yaml:82)
     "unetr_enc_512x512x128": dict(kind="unetr", vol=(512, 512, 128), patch=16, dim=768, depth=12, heads=12, batch=2),
+    "unetr_512x512x128": dict(kind="unetr", vol=(512, 512, 128), patch=16, dim=768, depth=12, heads=12, batch=2, decoder=True, fs=16, classes=4),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
@@ -73,7 +77,31 @@ def train_flops_per_unit(w):
     n = 1
     for s in w["vol"]:
         n *= s // w["patch"]
-    return 3 * (w["depth"] * _layer_flops(n, w["dim"]) + 2 * n * w["patch"] ** 3 * w["dim"])
+    fwd = w["depth"] * _layer_flops(n, w["dim"]) + 2 * n * w["patch"] ** 3 * w["dim"]
+    if w.get("decoder"):
+        fwd += unetr_decoder_fwd_flops(n, w["dim"], w["fs"], w["classes"])
+    return 3 * fwd
+
+
+def unetr_decoder_fwd_flops(n, D, fs, classes, in_chans=1):
+    """forward FLOPs of the skip-connection decoder on a grid of n tokens (monai block structure, simple/unetr_blocks.py): a residual block
+    Cin -> Cout at V voxels = 2 V (27 Cin Cout + 27 Cout^2 + [Cin != Cout] Cin Cout); a transposed 2x2x2 convolution Cin -> Cout FROM V
+    voxels = 2 V Cin 8 Cout"""
+    def res(v, ci, co):
+        return 2 * v * (27 * ci * co + 27 * co * co + (ci * co if ci != co else 0))
+
+    def up(v, ci, co):
+        return 2 * v * ci * 8 * co
+    v1, v2, v3, v4 = n * 8, n * 64, n * 512, n * 4096            # voxels after 1..4 upsamplings
+    f = res(v4, in_chans, fs)                                                                     # encoder1 (full resolution)
+    f += up(n, D, 2 * fs) + up(v1, 2 * fs, 2 * fs) + res(v2, 2 * fs, 2 * fs) + up(v2, 2 * fs, 2 * fs) + res(v3, 2 * fs, 2 * fs)   # encoder2
+    f += up(n, D, 4 * fs) + up(v1, 4 * fs, 4 * fs) + res(v2, 4 * fs, 4 * fs)                      # encoder3
+    f += up(n, D, 8 * fs)                                                                         # encoder4
+    f += up(n, D, 8 * fs) + res(v1, 16 * fs, 8 * fs)                                              # decoder5
+    f += up(v1, 8 * fs, 4 * fs) + res(v2, 8 * fs, 4 * fs)                                         # decoder4
+    f += up(v2, 4 * fs, 2 * fs) + res(v3, 4 * fs, 2 * fs)                                         # decoder3
+    f += up(v3, 2 * fs, fs) + res(v4, 2 * fs, fs)                                                 # decoder2
+    return f + 2 * v4 * fs * classes                                                              # 1x1 output convolution
 
 
 def source_hash():
@@ -150,7 +178,7 @@ class KernelProfiler:
     current stream): `gemm` = every ucfvit_gemm / ucfvit_gemm_grouped call, `attention` = every ucfvit_attention_fwd / _bwd call."""
 
     def __init__(self):
-        self.records = {"gemm": [], "attention": []}   # (start_evt, end_evt, algorithmic flops)
+        self.records = {"gemm": [], "attention": [], "conv": []}   # (start_evt, end_evt, algorithmic flops)
         self.enabled = False
 
     def _timed(self, family, fn, flops_of):
@@ -178,6 +206,13 @@ class KernelProfiler:
         ops.attention_fwd = self._timed("attention", ops.attention_fwd, lambda qkv, B, N, H, dh, scale: 4.0 * B * H * N * N * dh)
         ops.attention_bwd = self._timed("attention", ops.attention_bwd,
                                         lambda qkv, out, dout, lse, B, N, H, dh, scale: 8.0 * B * H * N * N * dh)
+
+        # 3x3x3 convolutions (csrc/conv3d.hip): 2 x 27 x voxels x Cin x Cout per forward / data-gradient / weight-gradient launch; the
+        # zero-padded channels of the 8-channel input operand are not credited
+        def conv_flops(x, w_packed, cout):
+            return 2.0 * 27 * (x.numel() // x.shape[-1]) * x.shape[-1] * cout
+        ops.conv3d_fwd = self._timed("conv", ops.conv3d_fwd, conv_flops)
+        ops.conv3d_wgrad = self._timed("conv", ops.conv3d_wgrad, lambda x, dy: 2.0 * 27 * (x.numel() // x.shape[-1]) * x.shape[-1] * dy.shape[-1])
 
     def summary(self, family):
         tot_ms, tot_flops = 0.0, 0.0
@@ -329,7 +364,27 @@ def build_workload(args, w, dev, rank):
     model = UNETR(img_size=vol, patch_size=w["patch"], in_chans=1, embed_dim=w["dim"], depth=w["depth"], num_heads=w["heads"],
                   class_token=False, twoD=False, num_classes=4, linear_decoder=False, feature_size=16, skip_connection=True,
                   FusedAttn_option=FusedAttn.HIP)
-    for n_, p_ in model.named_parameters():        # encoder workload: the conv decoder (MIOpen today) takes no part
+    if w.get("decoder"):
+        from UCF_VIT._hip import functional as HF
+        model = model.to(dev)
+        if not model.hip_decoder():
+            raise SystemExit("bench.py: the UNETR decoder of this configuration is not on the HIP convolution kernels")
+        x = torch.rand(B, 1, *vol, generator=g).to(dev)
+        labels = torch.randint(0, 4, (B, *vol), generator=g).to(dev)          # segmentation classes of every voxel, resident in HBM
+
+        def make_step(net, opt, sch):
+            def step():
+                loss = HF.dice_ce(net(x, None), labels)                       # DiceCELoss(to_onehot_y, softmax, squared_pred), train_unetr_simple.py:38
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                sch.step()
+                return loss
+            return step
+        desc = ("UNETR train step (12-Block encoder on 8192 tokens with taps 3/6/9, skip-connection conv decoder feature_size 16 up to 512x512x128, "
+                "Dice+CE on 4 classes; fwd+bwd+AdamW), synthetic volumes and labels resident in HBM")
+        return model, make_step, B, desc, 1e-5
+    for n_, p_ in model.named_parameters():        # encoder workload: the conv decoder takes no part
         if not n_.startswith(("blocks.", "patch_embed.", "token_embeds.", "norm.", "pos_embed")):
             p_.requires_grad_(False)
     model = model.to(dev)
@@ -489,16 +544,18 @@ def main():
         value = units / dt
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         fam = {}
-        for name in ("gemm", "attention"):
+        for name in ("gemm", "attention", "conv"):
             n_l, ms, fl = prof.summary(name)
             fam[name] = dict(launches=n_l, ms=ms, flops=fl, tflops=(fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0, share=ms * 1e-3 / dt)
         dom = max(fam, key=lambda k: fam[k]["ms"])
-        other = "attention" if dom == "gemm" else "gemm"
+        other = max((k for k in fam if k != dom), key=lambda k: fam[k]["ms"])
         kernel_names = {
             "gemm": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
                     "weight-gradient launch of the timed region)" % args.dtype,
             "attention": "fused attention kernels (attn_fwd / attn_bwd_dq / attn_bwd_dkv streaming for N > 208, attn_s3_fwd / attn_g_bwd "
                          "resident below): every forward and backward launch of the timed region, algorithmic FLOPs 4 / 8 B H N^2 dh",
+            "conv": "conv3_fwd_kernel / conv3_wgrad_kernel (csrc/conv3d.hip): 3x3x3 implicit-GEMM convolutions on MFMA, channels-last bf16 — every "
+                    "forward, data-gradient and weight-gradient launch of the timed region, algorithmic FLOPs 2 x 27 x voxels x Cin x Cout",
         }
         step_tflops = value / world * train_flops_per_unit(w) / 1e12
         traffic, traffic_src = pmc_traffic(args.workload, args.dtype, B, dom)

@@ -355,28 +355,32 @@ int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const f
 /* ------------------------------------------------------------------------------------------------------
  * UNETR convolutional decoder, convolutions.  Reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai's
  * blocks are chains of Conv3d(kernel 3, stride 1, padding 1, no bias) and ConvTranspose3d(kernel 2, stride 2, no bias); these entry
- * points replace torch.nn.functional.conv3d / conv_transpose3d (MIOpen) under them.
+ * points replace torch.nn.functional.conv3d / conv_transpose3d (MIOpen) under them, and the 1x1x1 layers (residual projections, the
+ * UnetOutBlock head, the transposed convolutions' channel mixing at small channel counts).
  * Activations are channels-last bf16 [B][X][Y][Z][C] (= torch.channels_last_3d memory of an [B, C, X, Y, Z] tensor).
  *
- * ucfvit_conv3d_fwd: y[v][co] = sum_{tap, ci} w[co][ci][tap] x[v + tap - 1][ci] (zero outside the volume), fp32 accumulation on MFMA.
- *   Cin in {8, 16, 32 k}, Cout = 16 k.  w_packed (bf16) holds the weights per 32-wide contraction step: with CPC = min(Cin, 32),
- *   TPS = 32 / CPC taps per step and NTS = ceil(27 / TPS) steps per channel chunk, w_packed[cc][ts][co][kk] = w[co][cc CPC + kk % CPC][tap]
- *   for tap = ts TPS + kk / CPC (zero when tap > 26); tap = (dx 3 + dy) 3 + dz.  The data gradient is the same call on dy with the
- *   flipped, transposed weights.
- * ucfvit_conv3d_wgrad: dw[tap][co][ci] = sum_v dy[v][co] x[v + tap - 1][ci] in fp32, written as [Cout / (16 MB)][Cin / CPC][27][16 MB][max(CPC, 16)]
- *   with MB = 2 when Cout % 32 == 0, else 1 (ucfvit_conv3d_wgrad_size floats; for CPC = 8 columns 8..15 are scratch).
- *   workspace: ucfvit_conv3d_wgrad_workspace bytes (per-workgroup partials, folded in a fixed order: deterministic).
+ * ucfvit_conv3d_fwd: y[v ldy + co] = bias[co] + sum_{tap, ci} w[co][ci][tap] x[v + tap - pad][ci] for co < cout_store (zero outside the
+ *   volume; ksize 3 with padding 1, or ksize 1 = a pointwise layer over tall-skinny voxel rows), fp32 accumulation on MFMA, output bf16 or
+ *   fp32 (out_dtype).  Cin in {8, 16, 32 k}, Cout = 16 k = the rows of w_packed; cout_store <= Cout channels are written with row stride
+ *   ldy (a 4-class head writes [V][4] from a 16-row weight block); bias fp32 [Cout] or NULL.
+ *   w_packed (bf16) holds the weights per 32-wide contraction step: with CPC = min(Cin, 32), TPS = 32 / CPC taps per step and
+ *   NTS = ceil(ksize^3 / TPS) steps per channel chunk, w_packed[cc][ts][co][kk] = w[co][cc CPC + kk % CPC][tap] for tap = ts TPS + kk / CPC
+ *   (zero when tap >= ksize^3); tap = (dx 3 + dy) 3 + dz.  The data gradient is the same call on dy with the flipped, transposed weights.
+ * ucfvit_conv3d_wgrad: dw[tap][co][ci] = sum_v dy[v][co] x[v + tap - pad][ci] in fp32, written as
+ *   [Cout / (16 MB)][Cin / CPC][ksize^3][16 MB][max(CPC, 16)] with MB = 2 when Cout % 32 == 0, else 1 (ucfvit_conv3d_wgrad_size floats; for
+ *   CPC = 8 columns 8..15 are scratch).  workspace: ucfvit_conv3d_wgrad_workspace bytes (per-workgroup partials, folded in a fixed order:
+ *   deterministic).
  * ucfvit_depth_to_space2: the transposed convolution is the GEMM x[V][Cin] * w[Cin][8 Cout] followed by this shuffle of
  *   cols [B Xi Yi Zi][(dx, dy, dz)][C] into out [B][2 Xi][2 Yi][2 Zi][C] (to_space = 1) — or its inverse for the backward pass (0).
  * ucfvit_pad_channels8: fp32 N C D H W input [B][C][S] with C <= 8 -> bf16 channels-last [B][S][8] (channels C..7 zero): the input volume as
  *   an operand of the kernels above.
  * ------------------------------------------------------------------------------------------------------ */
-int ucfvit_conv3d_fwd(const void* x, const void* w_packed, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout,
-                      void* stream);
-int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout);
-int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout);
+int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
+                      int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, void* stream);
+int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout, int ksize);
+int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize);
 int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y, int64_t Z,
-                        int64_t Cin, int64_t Cout, void* stream);
+                        int64_t Cin, int64_t Cout, int ksize, void* stream);
 int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int to_space, void* stream);
 int ucfvit_pad_channels8(const float* src, void* dst, int64_t B, int64_t C, int64_t S, void* stream);
 

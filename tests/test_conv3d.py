@@ -24,7 +24,7 @@ def test_pack_and_unpack_are_inverse_layouts():
     from UCF_VIT._hip import conv
     for cin, cout in ((8, 16), (16, 16), (32, 16), (64, 32), (128, 64)):
         w = torch.randn(cout, cin, 3, 3, 3)
-        p = conv.pack_conv3_weight(w).float()
+        p = conv.pack_conv_weight(w).float()
         cpc = min(cin, 32)
         tps = 32 // cpc
         for (co, ci, tap) in ((0, 0, 0), (cout - 1, cin - 1, 26), (3, cin // 2, 13), (5, 1, 7)):
@@ -35,7 +35,7 @@ def test_pack_and_unpack_are_inverse_layouts():
             assert p[0, -1, :, (27 % tps) * cpc:].abs().max() == 0
         mb16, nbk16 = (32 if cout % 32 == 0 else 16), max(cpc, 16)
         packed = torch.arange((cout // mb16) * (cin // cpc) * 27 * mb16 * nbk16, dtype=torch.float32)
-        u = conv.unpack_conv3_wgrad(packed, cin, cout)
+        u = conv.unpack_conv_wgrad(packed, cin, cout)
         co, ci, tap = cout - 2, cin - 3, 11
         idx = ((((co // mb16) * (cin // cpc) + ci // cpc) * 27 + tap) * mb16 + co % mb16) * nbk16 + ci % cpc
         assert u.reshape(cout, cin, 27)[co, ci, tap] == packed[idx]
@@ -106,7 +106,8 @@ def test_conv3x3x3_single_channel_input_through_the_padded_operand():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,X,Y,Z,cin,cout", [(2, 3, 4, 5, 768, 128), (1, 4, 4, 4, 128, 64), (1, 5, 6, 7, 32, 16), (1, 2, 3, 4, 768, 32)])
+@pytest.mark.parametrize("B,X,Y,Z,cin,cout", [(2, 3, 4, 5, 768, 128), (1, 4, 4, 4, 128, 64), (1, 5, 6, 7, 32, 16), (1, 2, 3, 4, 768, 32),
+                                              (2, 3, 5, 19, 64, 64), (1, 4, 4, 33, 64, 32), (1, 3, 3, 16, 32, 32)])
 def test_tconv2x2x2_forward_and_gradients(B, X, Y, Z, cin, cout):
     from UCF_VIT._hip import conv
     g = torch.Generator().manual_seed(cin + cout)
@@ -136,25 +137,29 @@ def test_depth_to_space_round_trip_is_exact():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout,bias,fp32", [(16, 4, True, True), (32, 16, False, False), (8, 16, False, False), (256, 128, False, False)])
+@pytest.mark.parametrize("cin,cout,bias,fp32", [(16, 4, True, True), (16, 3, True, True), (32, 16, False, False), (8, 16, False, False),
+                                                (256, 128, False, False), (64, 32, False, False), (128, 64, True, False)])
 def test_conv1x1x1_forward_and_gradients(cin, cout, bias, fp32):
+    """the tall-skinny layers through the 1x1x1 instance of the convolution kernels (any channel count below 128), the wide one through the GEMM"""
     from UCF_VIT._hip import conv
     g = torch.Generator().manual_seed(cin)
-    x = torch.randn(2, cin, 4, 5, 6, generator=g).bfloat16().cuda()
+    x = torch.randn(2, cin, 4, 5, 38, generator=g).bfloat16().cuda()
     w = (torch.randn(cout, cin, 1, 1, 1, generator=g) * cin ** -0.5).cuda()
     b = torch.randn(cout, generator=g).cuda() if bias else None
-    dy = torch.randn(2, cout, 4, 5, 6, generator=g).bfloat16().cuda()
+    dy = torch.randn(2, cout, 4, 5, 38, generator=g).bfloat16().cuda()
     xr, wr = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True)
-    br = b.bfloat16().float().requires_grad_(True) if bias else None
+    br = b.detach().clone().requires_grad_(True) if bias else None
     yr = F.conv3d(xr, wr, br)
     yr.backward(dy.float())
-    xc, wp = _cl(x).requires_grad_(True), w.clone().requires_grad_(True)
-    bp = b.clone().requires_grad_(True) if bias else None
+    want_dx = cin % 16 == 0
+    xc, wp = _cl(x).requires_grad_(want_dx), w.clone().requires_grad_(True)
+    bp = b.detach().clone().requires_grad_(True) if bias else None
     y = conv.conv1x1x1(xc, wp, bp, out_fp32=fp32)
-    assert y.shape == (2, 4, 5, 6, cout) and y.dtype == (torch.float32 if fp32 else torch.bfloat16)
+    assert y.shape == (2, 4, 5, 38, cout) and y.dtype == (torch.float32 if fp32 else torch.bfloat16) and y.is_contiguous()
     y.backward(_cl(dy).to(y.dtype))
     assert _rel(_ncdhw(y), yr) < (1e-4 if fp32 else 1e-2)
-    assert _rel(_ncdhw(xc.grad), xr.grad) < 1e-2
+    if want_dx:
+        assert _rel(_ncdhw(xc.grad), xr.grad) < 1e-2
     assert _rel(wp.grad, wr.grad) < 2e-3
     if bias:
         assert _rel(bp.grad, br.grad) < 2e-3

@@ -6,8 +6,9 @@ absent from the build container: PARITY UNPINNED against it; tests/test_conv3d.p
 
   conv3x3x3(x, w)        Conv3d(k=3, s=1, p=1, bias=False): forward and data gradient by ucfvit_conv3d_fwd (implicit GEMM, MFMA), weight
                          gradient by ucfvit_conv3d_wgrad (deterministic two-stage sum)
-  tconv2x2x2(x, w)       ConvTranspose3d(k=2, s=2, bias=False): GEMM [V, Cin] x [Cin, 8 Cout] + depth-to-space
-  conv1x1x1(x, w, b)     pointwise Conv3d: the GEMM of nn.Linear over the voxel rows
+  tconv2x2x2(x, w)       ConvTranspose3d(k=2, s=2, bias=False): pointwise layer [V, Cin] -> [V, 8 Cout] (GEMM or 1x1x1 kernel) + depth-to-space
+  conv1x1x1(x, w, b)     pointwise Conv3d: the 1x1x1 instance of the convolution kernels (tall-skinny voxel rows), the tiled GEMM of
+                         nn.Linear when both channel counts reach 128
   instnorm_act_cl        InstanceNorm3d (+ residual) + LeakyReLU on the channels-last layout
 """
 import torch
@@ -15,40 +16,101 @@ import torch
 from . import ops
 
 _DIRECT_CIN = (8, 16)
+GEMM_MIN = 128      # a pointwise / transposed layer goes to the tiled GEMM only when both channel counts reach its 128-wide tiles
 
 
 def conv3_cin_supported(cin):
     return cin in _DIRECT_CIN or (cin > 0 and cin % 32 == 0)
 
 
-def pack_conv3_weight(w):
-    """w [Cout, Cin, 3, 3, 3] (any float dtype) -> bf16 [Cin / CPC, NTS, Cout, 32] as ucfvit_conv3d_fwd reads it (include/ucfvit_hip.h):
-    CPC = min(Cin, 32) channels per contraction chunk, TPS = 32 / CPC taps per 32-wide step, NTS = ceil(27 / TPS) steps per chunk."""
+def _ceil_to(n, m):
+    return -(-n // m) * m
+
+
+def _pad_cin(c):
+    """smallest channel count >= c the convolution kernels accept as an input operand"""
+    return 8 if c <= 8 else 16 if c <= 16 else _ceil_to(c, 32)
+
+
+def pack_conv_weight(w):
+    """w [Cout, Cin, k, k, k] (k = 3 or 1, any float dtype) -> bf16 [Cin / CPC, NTS, Cout, 32] as ucfvit_conv3d_fwd reads it
+    (include/ucfvit_hip.h): CPC = min(Cin, 32) channels per contraction chunk, TPS = 32 / CPC taps per 32-wide step, NTS = ceil(k^3 / TPS)."""
     cout, cin = w.shape[0], w.shape[1]
+    nt = w.shape[2] * w.shape[3] * w.shape[4]
     if not conv3_cin_supported(cin):
-        raise ValueError(f"conv3x3x3: Cin must be 8, 16 or a multiple of 32, got {cin}")
+        raise ValueError(f"convolution kernels: Cin must be 8, 16 or a multiple of 32, got {cin}")
+    if nt not in (1, 27):
+        raise ValueError("convolution kernels: kernel size must be 1 or 3")
     cpc = min(cin, 32)
     tps = 32 // cpc
-    nts = -(-27 // tps)
-    wt = w.reshape(cout, cin, 27).permute(2, 0, 1)                     # [27, Cout, Cin]
-    if nts * tps > 27:
-        wt = torch.cat((wt, wt.new_zeros((nts * tps - 27, cout, cin))), 0)
+    nts = -(-nt // tps)
+    wt = w.reshape(cout, cin, nt).permute(2, 0, 1)                     # [taps, Cout, Cin]
+    if nts * tps > nt:
+        wt = torch.cat((wt, wt.new_zeros((nts * tps - nt, cout, cin))), 0)
     wt = wt.reshape(nts, tps, cout, cin // cpc, cpc).permute(3, 0, 2, 1, 4)   # [chunk, step, Cout, tap in step, channel in chunk]
     return wt.reshape(cin // cpc, nts, cout, 32).to(torch.bfloat16).contiguous()
 
 
+pack_conv3_weight = pack_conv_weight
+
+
 def pack_conv3_weight_dgrad(w):
     """the data gradient of a stride-1 'same' convolution is the convolution of dy with the flipped taps and swapped channel roles"""
-    return pack_conv3_weight(w.transpose(0, 1).flip(2, 3, 4))
+    return pack_conv_weight(w.transpose(0, 1).flip(2, 3, 4))
 
 
-def unpack_conv3_wgrad(packed, cin, cout):
-    """packed fp32 from ucfvit_conv3d_wgrad -> [Cout, Cin, 3, 3, 3]"""
+def unpack_conv_wgrad(packed, cin, cout, ksize=3):
+    """packed fp32 from ucfvit_conv3d_wgrad -> [Cout, Cin, k, k, k]"""
     cpc = min(cin, 32)
     mb16 = 32 if cout % 32 == 0 else 16
     nbk16 = max(cpc, 16)
-    t = packed.view(cout // mb16, cin // cpc, 27, mb16, nbk16)[..., :cpc]
-    return t.permute(0, 3, 1, 4, 2).reshape(cout, cin, 3, 3, 3)
+    nt = ksize ** 3
+    t = packed.view(cout // mb16, cin // cpc, nt, mb16, nbk16)[..., :cpc]
+    return t.permute(0, 3, 1, 4, 2).reshape(cout, cin, ksize, ksize, ksize)
+
+
+unpack_conv3_wgrad = unpack_conv_wgrad
+
+
+def _pad_last(t, c):
+    """[..., c0] -> contiguous bf16 [..., c] with zero columns appended"""
+    if t.shape[-1] == c and t.dtype == torch.bfloat16:
+        return t.contiguous()
+    out = torch.zeros(tuple(t.shape[:-1]) + (c,), dtype=torch.bfloat16, device=t.device)
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+def _colsum_narrow(d2):
+    """column sums of a tall matrix with few columns: fold rows into the column axis first so that every lane of ucfvit_colsum has a column
+    (its wave covers 512 bf16 columns), then add the folds"""
+    V, C = d2.shape
+    f = 1
+    while C * f < 512 and V % (2 * f) == 0:
+        f *= 2
+    return ops.colsum(d2.view(V // f, C * f)).view(f, C).sum(0)
+
+
+def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16):
+    """x [B, X, Y, Z, K] bf16 (K one of the kernels' input widths), w2 [N, K] float -> [B, X, Y, Z, cout_store] through the 1x1x1 kernel"""
+    n16 = _ceil_to(w2.shape[0], 16)
+    if n16 != w2.shape[0]:
+        w2 = torch.cat((w2, w2.new_zeros((n16 - w2.shape[0], w2.shape[1]))), 0)
+        if bias is not None:
+            bias = torch.cat((bias, bias.new_zeros(n16 - bias.numel())))
+    packed = pack_conv_weight(w2.reshape(n16, w2.shape[1], 1, 1, 1))
+    return ops.conv3d_fwd(x, packed, n16, ksize=1, bias=None if bias is None else bias.float().contiguous(), cout_store=cout_store,
+                          out_dtype=out_dtype)
+
+
+def _pointwise_wgrad(x, dy):
+    """x [.., K], dy [.., N] channels-last bf16 (kernel input widths) -> fp32 [N, K] = sum over voxels of dy^T x"""
+    K, N = x.shape[-1], dy.shape[-1]
+    if N % 16 == 0:
+        return unpack_conv_wgrad(ops.conv3d_wgrad(x, dy, ksize=1), K, N, 1).reshape(N, K)
+    if K % 16:
+        raise ValueError(f"pointwise weight gradient: one of the channel counts ({K}, {N}) must be a multiple of 16")
+    return unpack_conv_wgrad(ops.conv3d_wgrad(dy, x, ksize=1), N, K, 1).reshape(K, N).t()      # roles swapped: [K, N] = x^T dy
 
 
 class Conv3x3x3Fn(torch.autograd.Function):
@@ -66,7 +128,7 @@ class Conv3x3x3Fn(torch.autograd.Function):
             wk = torch.cat((w, w.new_zeros((cout, cin_x - cin, 3, 3, 3))), 1)   # zero-padded input channels (ops.pad_channels8)
         else:
             wk = w
-        y = ops.conv3d_fwd(x, pack_conv3_weight(wk.detach()), cout)
+        y = ops.conv3d_fwd(x, pack_conv_weight(wk.detach()), cout)
         ctx.save_for_backward(x, w)
         ctx.cin_x = cin_x
         return y
@@ -82,22 +144,32 @@ class Conv3x3x3Fn(torch.autograd.Function):
                 raise RuntimeError(f"conv3x3x3: no data gradient for a {cin}-channel input (the kernel writes multiples of 16 channels)")
             dx = ops.conv3d_fwd(dy, pack_conv3_weight_dgrad(w.detach()), cin)
         if ctx.needs_input_grad[1]:
-            dw = unpack_conv3_wgrad(ops.conv3d_wgrad(x, dy), ctx.cin_x, cout)[:, :cin].contiguous()
+            dw = unpack_conv_wgrad(ops.conv3d_wgrad(x, dy), ctx.cin_x, cout)[:, :cin].contiguous()
         return dx, dw
 
 
 class TConv2x2x2Fn(torch.autograd.Function):
+    """ConvTranspose3d(k=2, s=2): out[2v + d][co] = sum_ci x[v][ci] w[ci][co][d] = a pointwise layer to 8 Cout channels + depth-to-space.
+    Large channel counts (the 768-wide token maps) use the tiled GEMM; small ones the 1x1x1 convolution kernel."""
+
     @staticmethod
     def forward(ctx, x, w):
         cin, cout = w.shape[0], w.shape[1]
         if tuple(w.shape[2:]) != (2, 2, 2) or x.shape[-1] != cin:
             raise ValueError("tconv2x2x2: weight must be [Cin, Cout, 2, 2, 2] with Cin = the input's channels")
         B, X, Y, Z, _ = x.shape
-        w2 = w.detach().permute(2, 3, 4, 1, 0).reshape(8 * cout, cin).to(torch.bfloat16).contiguous()      # rows (dx, dy, dz, co)
-        cols = ops.linear_fwd(x.reshape(-1, cin), w2)
+        w2 = w.detach().permute(2, 3, 4, 1, 0).reshape(8 * cout, cin)                                        # rows (dx, dy, dz, co)
+        ctx.small = cin < GEMM_MIN
+        if ctx.small:
+            if not conv3_cin_supported(cin) or (8 * cout) % 32:
+                raise ValueError(f"tconv2x2x2: unsupported channel counts {cin} -> {cout}")
+            cols = _pointwise_fwd(x, w2, None, 8 * cout)
+        else:
+            w2 = w2.to(torch.bfloat16).contiguous()
+            cols = ops.linear_fwd(x.reshape(-1, cin), w2)
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(w.shape)
-        return ops.depth_to_space2(cols, B, X, Y, Z, cout)
+        return ops.depth_to_space2(cols.view(-1, 8 * cout), B, X, Y, Z, cout)
 
     @staticmethod
     def backward(ctx, dy):
@@ -105,58 +177,71 @@ class TConv2x2x2Fn(torch.autograd.Function):
         cin, cout = ctx.wshape[0], ctx.wshape[1]
         dcols = ops.space_to_depth2(dy.contiguous())
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.linear_dgrad(dcols, w2).view(x.shape)
+        if ctx.small:
+            dcols = dcols.view(tuple(x.shape[:-1]) + (8 * cout,))
+            if ctx.needs_input_grad[0]:
+                dx = _pointwise_fwd(dcols, w2.t(), None, cin)
+            if ctx.needs_input_grad[1]:
+                dw2 = _pointwise_wgrad(x, dcols)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = ops.linear_dgrad(dcols, w2).view(x.shape)
+            if ctx.needs_input_grad[1]:
+                dw2 = ops.linear_wgrad(dcols, x.reshape(-1, cin))                                            # [8 Cout, Cin] fp32
         if ctx.needs_input_grad[1]:
-            dw2 = ops.linear_wgrad(dcols, x.reshape(-1, cin))                                                # [8 Cout, Cin] fp32
-            dw = dw2.view(2, 2, 2, cout, cin).permute(4, 3, 0, 1, 2).contiguous()
+            dw = dw2.reshape(2, 2, 2, cout, cin).permute(4, 3, 0, 1, 2).contiguous()
         return dx, dw
 
 
 class Conv1x1x1Fn(torch.autograd.Function):
-    """pointwise convolution = nn.Linear over the voxel rows; `pad_to` output columns (zero weights) keep every GEMM operand 16-byte
-    aligned when Cout is small (the 1x1 output head)"""
+    """pointwise convolution over channels-last voxel rows.  The input may carry more channels than the weight (the zero-padded 8-channel
+    input volume); the output has exactly Cout channels (fp32 on request: the logits of the output head)."""
 
     @staticmethod
     def forward(ctx, x, w, b, out_fp32):
         cout, cin = w.shape[0], w.shape[1]
         cin_x = x.shape[-1]
-        w2 = w.detach().reshape(cout, cin).to(torch.bfloat16)
+        w2 = w.detach().reshape(cout, cin)
         if cin_x != cin:
             w2 = torch.cat((w2, w2.new_zeros((cout, cin_x - cin))), 1)
-        npad = -(-cout // 8) * 8
-        if npad != cout:
-            w2 = torch.cat((w2, w2.new_zeros((npad - cout, cin_x))), 0)
-        w2 = w2.contiguous()
-        bias = None
-        if b is not None:
-            bias = b.detach().to(torch.bfloat16)
-            if npad != cout:
-                bias = torch.cat((bias, bias.new_zeros(npad - cout)))
-        x2 = x.reshape(-1, cin_x)
-        y = ops.gemm(x2, w2, x2.shape[0], npad, cin_x, ops.LAYOUT_KC, ops.LAYOUT_KC, bias=bias,
-                     out_dtype=torch.float32 if out_fp32 else torch.bfloat16)
+        odt = torch.float32 if out_fp32 else torch.bfloat16
+        ctx.small = cin_x < GEMM_MIN or cout < GEMM_MIN
+        if ctx.small:
+            if not conv3_cin_supported(cin_x):
+                raise ValueError(f"conv1x1x1: unsupported input channel count {cin_x}")
+            y = _pointwise_fwd(x, w2, None if b is None else b.detach(), cout, odt)
+        else:
+            w2 = w2.to(torch.bfloat16).contiguous()
+            x2 = x.reshape(-1, cin_x)
+            y = ops.gemm(x2, w2, x2.shape[0], cout, cin_x, ops.LAYOUT_KC, ops.LAYOUT_KC, bias=None if b is None else b.detach().to(torch.bfloat16),
+                         out_dtype=odt).view(tuple(x.shape[:-1]) + (cout,))
         ctx.save_for_backward(x, w2)
-        ctx.dims = (cout, cin, npad, b is not None)
-        return y.view(tuple(x.shape[:-1]) + (npad,))[..., :cout]
+        ctx.dims = (cout, cin, b is not None)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w2 = ctx.saved_tensors
-        cout, cin, npad, has_b = ctx.dims
+        cout, cin, has_b = ctx.dims
         cin_x = x.shape[-1]
-        if npad != cout:
-            d2 = torch.zeros((dy.numel() // cout, npad), dtype=torch.bfloat16, device=dy.device)
-            d2[:, :cout] = dy.reshape(-1, cout)
+        dx = dw = db = None
+        if ctx.small:
+            dyp = _pad_last(dy, _pad_cin(cout))                       # bf16, channel count the kernels take as an input operand
+            if ctx.needs_input_grad[0]:
+                wt = torch.cat((w2.t(), w2.new_zeros((cin_x, dyp.shape[-1] - cout))), 1) if dyp.shape[-1] != cout else w2.t()
+                dx = _pointwise_fwd(dyp, wt, None, cin_x)
+            if ctx.needs_input_grad[1]:
+                dw = _pointwise_wgrad(x, dyp)[:cout, :cin].reshape(cout, cin, 1, 1, 1).contiguous()
+            if has_b and ctx.needs_input_grad[2]:
+                db = _colsum_narrow(dyp.view(-1, dyp.shape[-1]))[:cout].contiguous()
         else:
             d2 = dy.to(torch.bfloat16).reshape(-1, cout).contiguous()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.linear_dgrad(d2, w2).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(d2, x.reshape(-1, cin_x))[:cout, :cin].reshape(cout, cin, 1, 1, 1).contiguous()
-        if has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(d2)[:cout].contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = ops.linear_dgrad(d2, w2).view(x.shape)
+            if ctx.needs_input_grad[1]:
+                dw = ops.linear_wgrad(d2, x.reshape(-1, cin_x))[:, :cin].reshape(cout, cin, 1, 1, 1).contiguous()
+            if has_b and ctx.needs_input_grad[2]:
+                db = ops.colsum(d2)
         return dx, dw, db, None
 
 

@@ -607,33 +607,46 @@ def _chk_cl(t, name, C=None):
     return t
 
 
-def conv3d_fwd(x, w_packed, cout):
-    """x [B, X, Y, Z, Cin] bf16, w_packed from conv.pack_conv3_weight -> y [B, X, Y, Z, cout] bf16 (3x3x3, stride 1, zero padding 1)"""
+def conv_packed_numel(cin, cout, ksize):
+    cpc = min(cin, 32)
+    tps = 32 // cpc
+    return (cin // cpc) * (-(-(ksize ** 3) // tps)) * cout * 32
+
+
+def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=torch.bfloat16):
+    """x [B, X, Y, Z, Cin] bf16, w_packed from conv.pack_conv_weight (cout rows, a multiple of 16) -> y [B, X, Y, Z, cout_store] (ksize 3:
+    stride 1, zero padding 1; ksize 1: pointwise).  bias: fp32 [cout] or None."""
     L = _l.load()
     _chk_cl(x, "conv3d.x"), _chk(w_packed, "conv3d.w_packed")
     B, X, Y, Z, cin = x.shape
-    if w_packed.dtype != torch.bfloat16 or w_packed.numel() != (cin // min(cin, 32)) * (-(-27 // (32 // min(cin, 32)))) * cout * 32:
-        raise ValueError("conv3d: w_packed does not match (Cin, Cout)")
-    y = torch.empty((B, X, Y, Z, cout), dtype=torch.bfloat16, device=x.device)
-    _l.check(L.ucfvit_conv3d_fwd(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, X, Y, Z, cin, cout, _stream()), "ucfvit_conv3d_fwd")
+    if w_packed.dtype != torch.bfloat16 or w_packed.numel() != conv_packed_numel(cin, cout, ksize):
+        raise ValueError("conv3d: w_packed does not match (Cin, Cout, ksize)")
+    if bias is not None:
+        _chk(bias, "conv3d.bias")
+        if bias.dtype != torch.float32 or bias.numel() != cout:
+            raise ValueError("conv3d: bias must be fp32 [Cout]")
+    cs = cout if cout_store is None else cout_store
+    y = torch.empty((B, X, Y, Z, cs), dtype=out_dtype, device=x.device)
+    _l.check(L.ucfvit_conv3d_fwd(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), B, X, Y, Z, cin, cout, ksize, cs, cs, dt(y),
+                                 _stream()), "ucfvit_conv3d_fwd")
     return y
 
 
-def conv3d_wgrad(x, dy):
-    """-> packed fp32 weight gradient (conv.unpack_conv3_wgrad turns it into [Cout, Cin, 3, 3, 3])"""
+def conv3d_wgrad(x, dy, ksize=3):
+    """-> packed fp32 weight gradient (conv.unpack_conv_wgrad turns it into [Cout, Cin, k, k, k])"""
     L = _l.load()
     _chk_cl(x, "conv3d_wgrad.x"), _chk_cl(dy, "conv3d_wgrad.dy")
     B, X, Y, Z, cin = x.shape
     cout = dy.shape[-1]
     if dy.shape[:4] != x.shape[:4]:
         raise ValueError("conv3d_wgrad: x and dy must cover the same voxels")
-    n = L.ucfvit_conv3d_wgrad_size(cin, cout)
-    nbytes = L.ucfvit_conv3d_wgrad_workspace(B, X, Y, Z, cin, cout)
+    n = L.ucfvit_conv3d_wgrad_size(cin, cout, ksize)
+    nbytes = L.ucfvit_conv3d_wgrad_workspace(B, X, Y, Z, cin, cout, ksize)
     if n <= 0 or nbytes <= 0:
         raise ValueError(f"conv3d_wgrad: unsupported channel counts Cin={cin} Cout={cout}")
     dw = torch.empty(n, dtype=torch.float32, device=x.device)
     ws = workspace(nbytes, x.device)
-    _l.check(L.ucfvit_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, cin, cout, _stream()),
+    _l.check(L.ucfvit_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, cin, cout, ksize, _stream()),
              "ucfvit_conv3d_wgrad")
     return dw
 

@@ -1,5 +1,8 @@
-// Convolutions of the UNETR decoder for gfx950: 3x3x3 (stride 1, zero padding 1) as an implicit GEMM on
-// v_mfma_f32_16x16x32_bf16, plus the data movers of the 2x2x2 stride-2 transposed convolution (which itself is a plain GEMM).
+// Convolutions of the UNETR decoder for gfx950: 3x3x3 (stride 1, zero padding 1) and 1x1x1 as implicit GEMMs on
+// v_mfma_f32_16x16x32_bf16, plus the data movers of the 2x2x2 stride-2 transposed convolution (which itself is a 1x1x1 convolution to
+// 8 Cout channels, or a plain GEMM when the channel counts are large).  The 1x1x1 case exists because the decoder's pointwise layers are
+// tall and skinny (67 M voxels x 8..32 channels): a 128 x 128-tiled GEMM wastes 8..16x of its MFMA work on them and a weight gradient
+// with one output tile has no parallelism at all; here the voxel axis is the tiled one.
 //
 //   reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai UnetrBasicBlock / UnetrPrUpBlock / UnetrUpBlock are chains of
 //   Conv3d(k=3, s=1, p=1, bias=False) and ConvTranspose3d(k=2, s=2, bias=False).  monai is absent from the build container (PARITY UNPINNED
@@ -30,9 +33,11 @@ __device__ __forceinline__ f32x4 mma(const frag_t& a, const frag_t& b, const f32
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int CPC> struct CG {                        // CPC = channels per contraction chunk (8, 16 or 32)
+template <int CPC, int KS> struct CG {                // CPC = channels per contraction chunk (8, 16 or 32), KS = kernel size (3 or 1)
+    static constexpr int NT = KS * KS * KS;           // taps
+    static constexpr int PAD = KS / 2;
     static constexpr int TPS = 32 / CPC;              // taps folded into one 32-wide MFMA step
-    static constexpr int NTS = (27 + TPS - 1) / TPS;  // MFMA steps per chunk (27, 14, 7)
+    static constexpr int NTS = (NT + TPS - 1) / TPS;  // MFMA steps per chunk (KS 3: 27, 14, 7; KS 1: 1)
     static constexpr int VS = CPC * 2;                // bytes per voxel in the LDS image
     static constexpr int PPV = VS / 16;               // 16-byte pieces per voxel
 };
@@ -41,6 +46,7 @@ struct ConvGeo {
     int B, X, Y, Z, Cin, Cout;
     int tx, ty, tz;      // tile counts along x, y, z
     int tiles;           // B tx ty tz
+    int ldy, cout_store; // forward: output row stride (elements) and number of channels written (<= Cout)
 };
 
 // 16-byte load of 8 channels of voxel (b, gx, gy, gz), zero outside the volume (= the convolution's zero padding)
@@ -51,16 +57,16 @@ __device__ __forceinline__ u32x4 load_voxel(const bf16* __restrict__ x, const Co
     return v;
 }
 
-template <int CPC, int HX, int HY, int HZ>
+template <int CPC, int PAD, int HX, int HY, int HZ>
 __device__ __forceinline__ void stage_halo(char* halo, const bf16* __restrict__ x, const ConvGeo& g, int b, int x0, int y0, int z0, int ch0,
                                            int tid) {
-    typedef CG<CPC> G;
-    constexpr int NP = HX * HY * HZ * G::PPV;
+    constexpr int VS = CPC * 2, PPV = VS / 16;
+    constexpr int NP = HX * HY * HZ * PPV;
     for (int p = tid; p < NP; p += CT) {
-        const int hv = p / G::PPV, piece = p % G::PPV;
+        const int hv = p / PPV, piece = p % PPV;
         const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
-        *reinterpret_cast<u32x4*>(halo + hv * G::VS + piece * 16) =
-            load_voxel(x, g, b, x0 + hx - 1, y0 + hy - 1, z0 + hz - 1, g.Cin, ch0 + piece * 8);
+        *reinterpret_cast<u32x4*>(halo + hv * VS + piece * 16) =
+            load_voxel(x, g, b, x0 + hx - PAD, y0 + hy - PAD, z0 + hz - PAD, g.Cin, ch0 + piece * 8);
     }
 }
 
@@ -74,11 +80,11 @@ __device__ __forceinline__ void decode_tile(const ConvGeo& g, int t, int& b, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------- forward / data gradient
-template <int CPC, int NB, int TX, int TY>
-__global__ __launch_bounds__(CT) void conv3_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, bf16* __restrict__ y,
-                                                       ConvGeo g) {
-    typedef CG<CPC> G;
-    constexpr int HX = TX + 2, HY = TY + 2, HZ = 18;
+template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
+__global__ __launch_bounds__(CT) void conv_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                      OutT* __restrict__ y, ConvGeo g) {
+    typedef CG<CPC, KS> G;
+    constexpr int PAD = G::PAD, HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = 16 + 2 * PAD;
     constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
     constexpr int CB = 16 * NB;                     // output channels per workgroup
     constexpr int RPW = TX * TY / 4;                // 16-voxel rows per wave
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(CT) void conv3_fwd_kernel(const bf16* __restrict__ 
     const int nchunks = g.Cin / CPC;
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();
-        stage_halo<CPC, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cc * CPC, tid);
+        stage_halo<CPC, PAD, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cc * CPC, tid);
         for (int p = tid; p < G::NTS * CB * 4; p += CT) {
             const int piece = p & 3, row = (p >> 2) % CB, ts = (p >> 2) / CB;
             *reinterpret_cast<u32x4*>(wl + p * 16) =
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(CT) void conv3_fwd_kernel(const bf16* __restrict__ 
                 tap = 4 * ts + lg;
                 chb = 0;
             }
-            if (tap > 26) tap = 26;                             // padding step: its weights are zero, read any staged voxel
-            const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+            if (tap > G::NT - 1) tap = G::NT - 1;               // padding step: its weights are zero, read any staged voxel
+            const int dx = KS == 3 ? tap / 9 : 0, dy = KS == 3 ? (tap / 3) % 3 : 0, dz = KS == 3 ? tap % 3 : 0;
             const int boff = ((dx * HY + dy) * HZ + dz + li) * G::VS + chb;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
@@ -133,18 +139,29 @@ __global__ __launch_bounds__(CT) void conv3_fwd_kernel(const bf16* __restrict__ 
             }
         }
     }
-    // D[co = 4 lg + e][voxel = li]
+    // D[co = 4 lg + e][voxel = li]: 4 consecutive channels of one voxel per lane
+    const bool vec_ok = (g.ldy & 3) == 0;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
         if (gx < g.X && gy < g.Y && gz < g.Z) {
-            bf16* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.Cout + co0 + lg * 4;
+            OutT* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.ldy;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                bf16x4 o;
+                const int c = co0 + nb * 16 + lg * 4;
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[r][nb][e];
-                *reinterpret_cast<bf16x4*>(yp + nb * 16) = o;
+                for (int e = 0; e < 4; ++e) v[e] = acc[r][nb][e] + (bias ? bias[c + e] : 0.f);
+                if (c + 4 <= g.cout_store && vec_ok) {
+                    Vec4<OutT> o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.set(e, v[e]);
+                    *reinterpret_cast<Vec4<OutT>*>(yp + c) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < g.cout_store) yp[c + e] = from_f32<OutT>(v[e]);
+                }
             }
         }
     }
@@ -152,16 +169,18 @@ __global__ __launch_bounds__(CT) void conv3_fwd_kernel(const bf16* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
 constexpr int TZW = 32;       // z extent of a weight-gradient tile = one 32-deep contraction step per (x, y) row
-constexpr int WTAPS = 7;      // taps per wave (wave w owns taps w, w + 4, ...)
 
-template <int CPC, int MB, int TX, int TY>
-__global__ __launch_bounds__(CT) void conv3_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ part,
-                                                         ConvGeo g, int tiles_per_wg) {
-    typedef CG<CPC> G;
-    constexpr int HX = TX + 2, HY = TY + 2, HZ = TZW + 2;
+// KS 3: wave w owns taps w, w + 4, ... (7 accumulator sets) and walks every (x, y) row of the tile; ONE partial per workgroup.
+// KS 1: there is one tap, so the waves split the rows instead (row % 4 == wave) and each writes its own partial (4 per workgroup).
+template <int CPC, int MB, int TX, int TY, int KS>
+__global__ __launch_bounds__(CT) void conv_wgrad_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ part,
+                                                        ConvGeo g, int tiles_per_wg) {
+    typedef CG<CPC, KS> G;
+    constexpr int PAD = G::PAD, HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZW + 2 * PAD;
     constexpr int NBK = CPC >= 16 ? CPC / 16 : 1;
     constexpr int VSD = 32 * MB;                    // bytes per voxel of the dy image (16 MB channels)
     constexpr int DY_BYTES = TX * TY * TZW * VSD;
+    constexpr int WTAPS = KS == 3 ? 7 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* dyt = smem;
     char* halo = smem + DY_BYTES;
@@ -188,9 +207,9 @@ __global__ __launch_bounds__(CT) void conv3_wgrad_kernel(const bf16* __restrict_
             *reinterpret_cast<u32x4*>(dyt + v * VSD + piece * 16) =
                 load_voxel(dy, g, b, x0 + xl, y0 + yl, z0 + zl, g.Cout, cob * 16 * MB + piece * 8);
         }
-        stage_halo<CPC, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cib * CPC, tid);
+        stage_halo<CPC, PAD, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cib * CPC, tid);
         __syncthreads();
-        for (int row = 0; row < TX * TY; ++row) {
+        for (int row = (KS == 3 ? 0 : wave); row < TX * TY; row += (KS == 3 ? 1 : 4)) {
             const int xl = row / TY, yl = row % TY;
             frag_t a[MB];
 #pragma unroll
@@ -203,9 +222,9 @@ __global__ __launch_bounds__(CT) void conv3_wgrad_kernel(const bf16* __restrict_
             }
 #pragma unroll
             for (int k = 0; k < WTAPS; ++k) {
-                const int tap = wave + 4 * k;
-                if (tap < 27) {
-                    const int dx = tap / 9, dyy = (tap / 3) % 3, dz = tap % 3;
+                const int tap = KS == 3 ? wave + 4 * k : 0;
+                if (tap < G::NT) {
+                    const int dx = KS == 3 ? tap / 9 : 0, dyy = KS == 3 ? (tap / 3) % 3 : 0, dz = KS == 3 ? tap % 3 : 0;
                     const char* bp = halo + ((((xl + dx) * HY + yl + dyy) * HZ) + dz + 8 * lg + q) * G::VS + 4 * p4 * 2;
 #pragma unroll
                     for (int nb = 0; nb < NBK; ++nb) {
@@ -220,13 +239,14 @@ __global__ __launch_bounds__(CT) void conv3_wgrad_kernel(const bf16* __restrict_
             }
         }
     }
-    // partial [blockIdx.x][blockIdx.y][tap][16 MB][16 NBK]; D[co = 4 lg + e][ci = li]
+    // partial [slot][blockIdx.y][tap][16 MB][16 NBK] with slot = the workgroup (KS 3) or (workgroup, wave) (KS 1); D[co = 4 lg + e][ci = li]
     constexpr int PB = 16 * MB * 16 * NBK;
-    float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 27 * PB;
+    const int slot = KS == 3 ? blockIdx.x : blockIdx.x * 4 + wave;
+    float* out = part + ((int64_t)slot * gridDim.y + blockIdx.y) * G::NT * PB;
 #pragma unroll
     for (int k = 0; k < WTAPS; ++k) {
-        const int tap = wave + 4 * k;
-        if (tap < 27) {
+        const int tap = KS == 3 ? wave + 4 * k : 0;
+        if (tap < G::NT) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -277,55 +297,67 @@ __global__ __launch_bounds__(CT) void pad8_kernel(const float* __restrict__ src,
 }
 
 int conv_check(const char* name, const void* x, const void* w, const void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
-               int64_t Cout) {
+               int64_t Cout, int ksize) {
     UCF_CHECK_ARG(x && w && y, "%s: null pointer", name);
     UCF_CHECK_ARG(B > 0 && X > 0 && Y > 0 && Z > 0, "%s: empty volume", name);
     UCF_CHECK_ARG(B * X * Y * Z < (1ll << 31), "%s: more than 2^31 voxels", name);
+    UCF_CHECK_ARG(ksize == 1 || ksize == 3, "%s: kernel size must be 1 or 3 (got %d)", name, ksize);
     UCF_CHECK_ARG(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0), "%s: Cin must be 8, 16 or a multiple of 32 (got %lld)", name, (long long)Cin);
     UCF_CHECK_ARG(Cout > 0 && Cout % 16 == 0, "%s: Cout must be a multiple of 16 (got %lld)", name, (long long)Cout);
-    UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(w) && (((uintptr_t)y) & 7) == 0, "%s: operands must be 16-byte aligned", name);
+    UCF_CHECK_ARG(ucf_is_aligned16(x) && ucf_is_aligned16(w) && ucf_is_aligned16(y), "%s: operands must be 16-byte aligned", name);
     return UCFVIT_OK;
 }
 
-template <int CPC, int NB, int TX, int TY>
-int launch_fwd(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, hipStream_t s) {
-    typedef CG<CPC> G;
+template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
+int launch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGeo g, hipStream_t s) {
+    typedef CG<CPC, KS> G;
     g.tx = (g.X + TX - 1) / TX;
     g.ty = (g.Y + TY - 1) / TY;
     g.tz = (g.Z + 15) / 16;
     const int64_t tiles = (int64_t)g.B * g.tx * g.ty * g.tz;
     UCF_CHECK_ARG(tiles < (1ll << 31) && g.Cout / (16 * NB) < 65536, "ucfvit_conv3d_fwd: grid too large");
     g.tiles = (int)tiles;
-    constexpr int SMEM = (TX + 2) * (TY + 2) * 18 * G::VS + G::NTS * 16 * NB * 64;
+    constexpr int SMEM = (TX + 2 * G::PAD) * (TY + 2 * G::PAD) * (16 + 2 * G::PAD) * G::VS + G::NTS * 16 * NB * 64;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3_fwd_kernel<CPC, NB, TX, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<CPC, NB, TX, TY, KS, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3_fwd_kernel<CPC, NB, TX, TY>), dim3(g.tiles, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp, y, g);
+    hipLaunchKernelGGL((conv_fwd_kernel<CPC, NB, TX, TY, KS, OutT>), dim3(g.tiles, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp, bias, y, g);
     UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
     return UCFVIT_OK;
 }
 
-template <int CPC, int MB, int TX, int TY> struct WG {
+template <int CPC, int KS, typename OutT>
+int dispatch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, const ConvGeo& g, hipStream_t s) {
+    const int nb16 = g.Cout / 16;
+    if (nb16 % 4 == 0) return launch_fwd<CPC, 4, 2, 4, KS, OutT>(x, wp, bias, y, g, s);
+    if (nb16 % 2 == 0) return launch_fwd<CPC, 2, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
+    return launch_fwd<CPC, 1, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
+}
+
+template <int CPC, int MB, int TX, int TY, int KS> struct WG {
     static constexpr int NBK = CPC >= 16 ? CPC / 16 : 1;
     static constexpr int PB = 16 * MB * 16 * NBK;
-    static constexpr int SMEM = TX * TY * TZW * 32 * MB + (TX + 2) * (TY + 2) * (TZW + 2) * CG<CPC>::VS + 64;
+    static constexpr int PAD = KS / 2;
+    static constexpr int SMEM = TX * TY * TZW * 32 * MB + (TX + 2 * PAD) * (TY + 2 * PAD) * (TZW + 2 * PAD) * CPC * 2 + 64;
+    static constexpr int SLOTS = KS == 3 ? 1 : 4;          // partials per workgroup
 };
 
 constexpr int64_t WGRAD_PART_FLOATS = 32ll << 20;      // cap of the partial-sum scratch (128 MiB)
 
 // geometry shared by the workspace query and the launch
-template <int CPC, int MB, int TX, int TY>
+template <int CPC, int MB, int TX, int TY, int KS>
 void wgrad_plan(ConvGeo& g, int& n_wg, int& tiles_per_wg, int& gy, int64_t& n_out) {
+    typedef WG<CPC, MB, TX, TY, KS> W;
     g.tx = (g.X + TX - 1) / TX;
     g.ty = (g.Y + TY - 1) / TY;
     g.tz = (g.Z + TZW - 1) / TZW;
     g.tiles = g.B * g.tx * g.ty * g.tz;
     gy = (g.Cin / CPC) * (g.Cout / (16 * MB));
-    n_out = (int64_t)gy * 27 * WG<CPC, MB, TX, TY>::PB;
-    int64_t cap = WGRAD_PART_FLOATS / n_out;
+    n_out = (int64_t)gy * CG<CPC, KS>::NT * W::PB;
+    int64_t cap = WGRAD_PART_FLOATS / (n_out * W::SLOTS);
     if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
     n_wg = (int)(g.tiles < cap ? g.tiles : cap);
@@ -333,85 +365,87 @@ void wgrad_plan(ConvGeo& g, int& n_wg, int& tiles_per_wg, int& gy, int64_t& n_ou
     n_wg = (g.tiles + tiles_per_wg - 1) / tiles_per_wg;
 }
 
-template <int CPC, int MB, int TX, int TY>
+template <int CPC, int MB, int TX, int TY, int KS>
 int launch_wgrad(const bf16* x, const bf16* dy, float* dw, float* ws, ConvGeo g, hipStream_t s) {
+    typedef WG<CPC, MB, TX, TY, KS> W;
     int n_wg, tpw, gy;
     int64_t n_out;
-    wgrad_plan<CPC, MB, TX, TY>(g, n_wg, tpw, gy, n_out);
-    constexpr int SMEM = WG<CPC, MB, TX, TY>::SMEM;
+    wgrad_plan<CPC, MB, TX, TY, KS>(g, n_wg, tpw, gy, n_out);
+    constexpr int SMEM = W::SMEM;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3_wgrad_kernel<CPC, MB, TX, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<CPC, MB, TX, TY, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3_wgrad_kernel<CPC, MB, TX, TY>), dim3(n_wg, gy), dim3(CT), SMEM, s, x, dy, ws, g, tpw);
+    hipLaunchKernelGGL((conv_wgrad_kernel<CPC, MB, TX, TY, KS>), dim3(n_wg, gy), dim3(CT), SMEM, s, x, dy, ws, g, tpw);
     UCF_LAUNCH_CHECK("ucfvit_conv3d_wgrad");
-    return ucfvit_reduce_rows(ws, dw, n_wg, n_out, 0, s);
+    return ucfvit_reduce_rows(ws, dw, (int64_t)n_wg * W::SLOTS, n_out, 0, s);
 }
 
 // which instantiation serves (Cin, Cout):  CPC = min(Cin, 32);  forward NB = largest of 4, 2, 1 dividing Cout / 16;  weight gradient MB = 2
 // when Cout % 32 == 0
-#define CONV_CPC_SWITCH(CIN, ...)              \
-    do {                                       \
-        if ((CIN) == 8) {                      \
-            constexpr int CPC_ = 8;            \
-            __VA_ARGS__                        \
-        } else if ((CIN) == 16) {              \
-            constexpr int CPC_ = 16;           \
-            __VA_ARGS__                        \
-        } else {                               \
-            constexpr int CPC_ = 32;           \
-            __VA_ARGS__                        \
-        }                                      \
+#define CONV_SWITCH(CIN, KSIZE, ...)                                         \
+    do {                                                                     \
+        if ((KSIZE) == 3) {                                                  \
+            constexpr int KS_ = 3;                                           \
+            if ((CIN) == 8) { constexpr int CPC_ = 8; __VA_ARGS__ }          \
+            else if ((CIN) == 16) { constexpr int CPC_ = 16; __VA_ARGS__ }   \
+            else { constexpr int CPC_ = 32; __VA_ARGS__ }                    \
+        } else {                                                             \
+            constexpr int KS_ = 1;                                           \
+            if ((CIN) == 8) { constexpr int CPC_ = 8; __VA_ARGS__ }          \
+            else if ((CIN) == 16) { constexpr int CPC_ = 16; __VA_ARGS__ }   \
+            else { constexpr int CPC_ = 32; __VA_ARGS__ }                    \
+        }                                                                    \
     } while (0)
 
 }  // namespace
 
-// x [B][X][Y][Z][Cin] bf16, w_packed [Cin/CPC][NTS][Cout][32] bf16 -> y [B][X][Y][Z][Cout] bf16
-extern "C" int ucfvit_conv3d_fwd(const void* x, const void* w_packed, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
-                                 int64_t Cout, void* stream) {
-    if (int rc = conv_check("ucfvit_conv3d_fwd", x, w_packed, y, B, X, Y, Z, Cin, Cout)) return rc;
-    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0};
+// x [B][X][Y][Z][Cin] bf16, w_packed [Cin/CPC][NTS][Cout][32] bf16, bias fp32 [Cout] or NULL -> y[voxel * ldy + co] for co < cout_store
+extern "C" int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z,
+                                 int64_t Cin, int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, void* stream) {
+    if (int rc = conv_check("ucfvit_conv3d_fwd", x, w_packed, y, B, X, Y, Z, Cin, Cout, ksize)) return rc;
+    UCF_CHECK_ARG(cout_store > 0 && cout_store <= Cout && ldy >= cout_store && ldy < (1ll << 31), "ucfvit_conv3d_fwd: need 0 < cout_store <= Cout, ldy >= cout_store");
+    UCF_CHECK_ARG(out_dtype == UCFVIT_BF16 || out_dtype == UCFVIT_F32, "ucfvit_conv3d_fwd: bad out_dtype %d", out_dtype);
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, (int)ldy, (int)cout_store};
     hipStream_t s = (hipStream_t)stream;
-    const int nb16 = (int)(Cout / 16);
-    CONV_CPC_SWITCH(Cin, {
-        if (nb16 % 4 == 0) return launch_fwd<CPC_, 4, 2, 4>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, g, s);
-        if (nb16 % 2 == 0) return launch_fwd<CPC_, 2, 2, 8>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, g, s);
-        return launch_fwd<CPC_, 1, 2, 8>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, g, s);
+    CONV_SWITCH(Cin, ksize, {
+        if (out_dtype == UCFVIT_BF16) return dispatch_fwd<CPC_, KS_, bf16>((const bf16*)x, (const bf16*)w_packed, bias, (bf16*)y, g, s);
+        return dispatch_fwd<CPC_, KS_, float>((const bf16*)x, (const bf16*)w_packed, bias, (float*)y, g, s);
     });
     return UCFVIT_OK;
 }
 
-// number of fp32 values of the packed weight gradient [Cin/CPC * Cout/(16 MB)][27][16 MB][16 NBK] and bytes of scratch for the partials
-extern "C" int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout) {
+// number of fp32 values of the packed weight gradient [Cout/(16 MB)][Cin/CPC][taps][16 MB][16 NBK] and bytes of scratch for the partials
+extern "C" int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout, int ksize) {
     const int64_t cpc = Cin < 32 ? Cin : 32;
     const int64_t nbk16 = cpc >= 16 ? cpc : 16;
-    return (Cin / cpc) * 27 * Cout * nbk16;
+    return (Cin / cpc) * (ksize == 3 ? 27 : 1) * Cout * nbk16;
 }
-extern "C" int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout) {
-    if (!(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0)) || Cout <= 0 || Cout % 16) return 0;
-    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0};
+extern "C" int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize) {
+    if (!(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0)) || Cout <= 0 || Cout % 16 || !(ksize == 1 || ksize == 3)) return 0;
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, 0, 0};
     int n_wg = 0, tpw = 0, gy = 0;
     int64_t n_out = 0;
-    CONV_CPC_SWITCH(Cin, {
+    CONV_SWITCH(Cin, ksize, {
         if (Cout % 32 == 0)
-            wgrad_plan<CPC_, 2, 2, 4>(g, n_wg, tpw, gy, n_out);
+            wgrad_plan<CPC_, 2, 2, 4, KS_>(g, n_wg, tpw, gy, n_out);
         else
-            wgrad_plan<CPC_, 1, 2, 4>(g, n_wg, tpw, gy, n_out);
+            wgrad_plan<CPC_, 1, 2, 4, KS_>(g, n_wg, tpw, gy, n_out);
     });
-    return (int64_t)n_wg * n_out * (int64_t)sizeof(float);
+    return (int64_t)n_wg * (ksize == 3 ? 1 : 4) * n_out * (int64_t)sizeof(float);
 }
-// x [..][Cin], dy [..][Cout] bf16 -> dw_packed fp32 (layout above; UCF_VIT/_hip/conv.py:unpack_conv3_wgrad turns it into [Cout][Cin][3][3][3])
+// x [..][Cin], dy [..][Cout] bf16 -> dw_packed fp32 (layout above; UCF_VIT/_hip/conv.py:unpack_conv_wgrad turns it into [Cout][Cin][k][k][k])
 extern "C" int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y,
-                                   int64_t Z, int64_t Cin, int64_t Cout, void* stream) {
-    if (int rc = conv_check("ucfvit_conv3d_wgrad", x, dy, dw_packed, B, X, Y, Z, Cin, Cout)) return rc;
+                                   int64_t Z, int64_t Cin, int64_t Cout, int ksize, void* stream) {
+    if (int rc = conv_check("ucfvit_conv3d_wgrad", x, dy, dw_packed, B, X, Y, Z, Cin, Cout, ksize)) return rc;
     UCF_CHECK_ARG(workspace, "ucfvit_conv3d_wgrad: null workspace");
-    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0};
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
-    CONV_CPC_SWITCH(Cin, {
-        if (Cout % 32 == 0) return launch_wgrad<CPC_, 2, 2, 4>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
-        return launch_wgrad<CPC_, 1, 2, 4>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
+    CONV_SWITCH(Cin, ksize, {
+        if (Cout % 32 == 0) return launch_wgrad<CPC_, 2, 2, 4, KS_>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
+        return launch_wgrad<CPC_, 1, 2, 4, KS_>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
     });
     return UCFVIT_OK;
 }
