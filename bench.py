@@ -207,12 +207,12 @@ class KernelProfiler:
         ops.attention_bwd = self._timed("attention", ops.attention_bwd,
                                         lambda qkv, out, dout, lse, B, N, H, dh, scale: 8.0 * B * H * N * N * dh)
 
-        # 3x3x3 convolutions (csrc/conv3d.hip): 2 x 27 x voxels x Cin x Cout per forward / data-gradient / weight-gradient launch; the
-        # zero-padded channels of the 8-channel input operand are not credited
-        def conv_flops(x, w_packed, cout):
-            return 2.0 * 27 * (x.numel() // x.shape[-1]) * x.shape[-1] * cout
+        # 3x3x3 and 1x1x1 convolutions (csrc/conv3d.hip): 2 x taps x voxels x Cin x Cout per forward / data-gradient / weight-gradient
+        # launch, with the operand widths as launched (the zero channels of the 8-channel input operand are 1 % of the total)
+        def conv_flops(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=None):
+            return 2.0 * ksize ** 3 * x.numel() * (cout_store or cout)
         ops.conv3d_fwd = self._timed("conv", ops.conv3d_fwd, conv_flops)
-        ops.conv3d_wgrad = self._timed("conv", ops.conv3d_wgrad, lambda x, dy: 2.0 * 27 * (x.numel() // x.shape[-1]) * x.shape[-1] * dy.shape[-1])
+        ops.conv3d_wgrad = self._timed("conv", ops.conv3d_wgrad, lambda x, dy, ksize=3: 2.0 * ksize ** 3 * x.numel() * dy.shape[-1])
 
     def summary(self, family):
         tot_ms, tot_flops = 0.0, 0.0
@@ -278,13 +278,35 @@ def cpu_baseline(wname, w, steps=5):
         what = (f"{wname} fp32 CPU oracle encoder step on a 128^3 crop (512 tokens), scaled to whole volumes by algorithmic FLOPs "
                 f"(x{scale:.5f})")
 
-        def one():
-            feats, taps = R.vit_forward_intermediates(m, x, taps_at)
-            loss = feats.square().mean() + sum(t.square().mean() for t in taps)
-            loss.backward()
-            opt.step()
-            opt.zero_grad()
-            sch.step()
+        if w.get("decoder"):
+            # whole model: the decoder restated in oracle/unetr_decoder_ref.py over parameters of the shapes the model declares
+            from oracle import unetr_decoder_ref as D
+            from UCF_VIT.simple.arch import UNETR
+            shapes = UNETR(img_size=list(crop), patch_size=w["patch"], in_chans=1, embed_dim=w["dim"], depth=1, num_heads=w["heads"], class_token=False,
+                           twoD=False, num_classes=w["classes"], linear_decoder=False, feature_size=w["fs"], skip_connection=True).state_dict()
+            dec = {k: torch.nn.Parameter(v.detach().float().clone()) for k, v in shapes.items() if k.startswith(("encoder", "decoder", "out."))}
+            opt = torch.optim.AdamW(list(m.parameters()) + list(dec.values()), lr=1e-4, betas=(0.9, 0.95), weight_decay=1e-5)
+            sch = R.WarmupCosineLR(opt, 1000, 20000, 1e-8, 1e-8)
+            labels = torch.randint(0, w["classes"], (batch, *crop), generator=g)
+            fz = tuple(c // w["patch"] for c in crop)
+            what = (f"{wname} fp32 CPU oracle whole-model step (encoder + conv decoder + Dice/CE) on a 128^3 crop, scaled to whole volumes by "
+                    f"algorithmic FLOPs (x{scale:.5f})")
+
+            def one():
+                feats, taps = R.vit_forward_intermediates(m, x, taps_at)
+                loss = D.dice_ce_loss(D.unetr_head(dec, x, feats, taps, fz, w["dim"]), labels)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                sch.step()
+        else:
+            def one():
+                feats, taps = R.vit_forward_intermediates(m, x, taps_at)
+                loss = feats.square().mean() + sum(t.square().mean() for t in taps)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                sch.step()
     t0 = time.perf_counter()
     one()     # warm-up
     warm = time.perf_counter() - t0

@@ -42,3 +42,42 @@ def dice_ce_loss(logits, label, smooth_nr=1e-5, smooth_dr=1e-5):
     denom = (prob ** 2).sum(dims) + (onehot ** 2).sum(dims)
     dice = 1.0 - (2.0 * inter + smooth_nr) / (denom + smooth_dr)
     return dice.mean() + F.cross_entropy(logits.float(), label)
+
+
+# ---- the whole skip-connection decoder (reference wiring: src/UCF_VIT/simple/arch.py:951-993 unetr_head / proj_feat, blocks :808-940) ----
+def proj_feat(tokens, feat_size, hidden):
+    """arch.py:951-958: [B, N, D] -> [B, D, *feat_size]"""
+    x = tokens.float().view(tokens.size(0), *feat_size, hidden)
+    return x.permute(0, len(feat_size) + 1, *range(1, len(feat_size) + 1)).contiguous()
+
+
+def _res(p, prefix, inp):
+    w3 = p.get(prefix + ".conv3.conv.weight")
+    return res_block(inp, p[prefix + ".conv1.conv.weight"], p[prefix + ".conv2.conv.weight"], w3)
+
+
+def _pr_up(p, prefix, x, num_layer):
+    """monai UnetrPrUpBlock: transposed conv (k 2, s 2), then num_layer x [transposed conv, UnetResBlock]"""
+    x = F.conv_transpose3d(x, p[prefix + ".transp_conv_init.conv.weight"], stride=2)
+    for i in range(num_layer):
+        x = F.conv_transpose3d(x, p[f"{prefix}.blocks.{i}.0.conv.weight"], stride=2)
+        x = _res(p, f"{prefix}.blocks.{i}.1", x)
+    return x
+
+
+def _up(p, prefix, inp, skip):
+    """monai UnetrUpBlock: transposed conv, concatenate the skip, UnetResBlock"""
+    out = F.conv_transpose3d(inp, p[prefix + ".transp_conv.conv.weight"], stride=2)
+    return _res(p, prefix + ".conv_block", torch.cat((out, skip), dim=1))
+
+
+def unetr_head(p, img, feats, taps, feat_size, hidden):
+    """arch.py:981-993 (skip_connection=True, full-resolution grid): p = the model's state_dict (fp32), img [B, C, X, Y, Z], feats = the
+    final-normed tokens, taps = the three intermediate token maps (blocks depth/4, 2 depth/4, 3 depth/4) -> logits [B, classes, X, Y, Z]"""
+    enc1 = _res(p, "encoder1.layer", img.float())
+    dec4 = proj_feat(feats, feat_size, hidden)
+    dec3 = _up(p, "decoder5", dec4, _pr_up(p, "encoder4", proj_feat(taps[2], feat_size, hidden), 0))
+    dec2 = _up(p, "decoder4", dec3, _pr_up(p, "encoder3", proj_feat(taps[1], feat_size, hidden), 1))
+    dec1 = _up(p, "decoder3", dec2, _pr_up(p, "encoder2", proj_feat(taps[0], feat_size, hidden), 2))
+    out = _up(p, "decoder2", dec1, enc1)
+    return F.conv3d(out, p["out.conv.conv.weight"], p["out.conv.conv.bias"])

@@ -297,3 +297,41 @@ def test_unetr_encoder_full_size_512x512x128():
     for n, p in m.named_parameters():
         if n.startswith(("blocks.", "patch_embed.", "norm.", "pos_embed")):
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_unetr_whole_model_full_size_512x512x128():
+    """BASELINE config 5 complete: encoder + skip-connection convolutional decoder (HIP convolution kernels, channels-last bf16) + Dice/CE at
+    512 x 512 x 128 on one GPU.  Size-independent properties: logits of the reference's shape [B, classes, X, Y, Z], finite; at random
+    initialisation the loss sits near ln(classes) + mean dice of a near-uniform prediction; two runs are bit-identical; every parameter of
+    the model receives a finite gradient; the loss gradient of the logits sums to ~0 over the classes of a voxel (softmax + dice both do)."""
+    from UCF_VIT.simple.arch import UNETR
+    from UCF_VIT._hip import functional as HF
+    img = [512, 512, 128]
+    torch.manual_seed(11)
+    m = UNETR(img_size=img, **UNETR_KW).to(DEV)
+    m.set_compute_dtype(torch.bfloat16)
+    assert m.hip_decoder()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(1, 1, *img, generator=g).to(DEV)
+    lab = torch.randint(0, 4, (1, *img), generator=g).to(DEV)
+    logits = m(x, None)
+    assert tuple(logits.shape) == (1, 4, *img) and logits.dtype == torch.float32
+    assert torch.isfinite(logits).all()
+    lg = logits.detach().requires_grad_(True)
+    loss_probe = HF.dice_ce(lg, lab)
+    loss_probe.backward()
+    assert float(lg.grad.sum(dim=1).abs().max()) < 1e-6 * max(1.0, float(lg.grad.abs().max()) * 1e6)
+    loss = HF.dice_ce(logits, lab)
+    assert 1.0 < loss.item() < 4.0                        # ln 4 = 1.39 for a uniform prediction, + a dice term in (0, 1); random init is not far off
+    with torch.no_grad():
+        logits2 = m(x, None)
+    assert torch.equal(logits, logits2)
+    loss.backward()
+    from UCF_VIT._hip.functional import flush_wgrads
+    flush_wgrads()
+    n_dec = 0
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        n_dec += n.startswith(("encoder", "decoder", "out."))
+    assert n_dec == 33                                     # every convolution of the decoder: 12 blocks + the output head
+    assert torch.cuda.max_memory_allocated() < 120 * 2 ** 30

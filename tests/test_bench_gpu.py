@@ -58,3 +58,12 @@ def test_bench_unetr_volume_workload_line():
     assert "attention" in d["roofline"]["kernel"] or "gemm3_kernel" in d["roofline"]["kernel"]
     assert d["roofline"]["other_family"]["launches"] > 0
     assert d["cpu_baseline"]["unit"] == "volumes/sec" and "crop" in d["cpu_baseline"]["sample"]
+
+
+def test_bench_unetr_whole_model_line():
+    """configs[4] complete (encoder + conv decoder + Dice/CE): the dominant family is the convolution kernels; no CPU leg here (the whole-model
+    oracle step takes ~10 s per step on the host; tests/test_unetr_decoder_model.py checks that oracle against the HIP model)"""
+    d = _bench(["--steps", "2", "--warmup", "1", "--workload", "unetr_512x512x128", "--batch", "1", "--no-cpu-baseline"])
+    _check(d, 1, "volumes/sec")
+    assert "conv" in d["roofline"]["kernel"] and d["roofline"]["launches"] > 40
+    assert "decoder" in d["config"]["workload"]

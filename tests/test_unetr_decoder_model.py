@@ -117,3 +117,32 @@ def test_unetr_hip_decoder_trains():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+@pytest.mark.gpu
+def test_unetr_whole_model_vs_cpu_oracle():
+    """encoder (oracle/ucf_vit_ref.py) + decoder (oracle/unetr_decoder_ref.py: F.conv3d / F.conv_transpose3d / F.instance_norm) + Dice/CE on
+    the host in fp32 against the HIP model in bf16 with the same weights: logits 3e-2 (norm-relative), loss 2e-2"""
+    from oracle import ucf_vit_ref as R
+    from oracle import unetr_decoder_ref as D
+    from UCF_VIT._hip import functional as HF
+    img = [32, 32, 32]
+    m = _model(img, seed=7)
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref = R.VIT(img, patch_size=16, in_chans=1, num_classes=None, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False)
+    missing = ref.load_state_dict({k: v for k, v in sd.items() if k in ref.state_dict()}, strict=False)
+    assert not missing.missing_keys, missing.missing_keys
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 1, *img, generator=g)
+    lab = torch.randint(0, 4, (2, *img), generator=g)
+    with torch.no_grad():
+        feats, taps = R.vit_forward_intermediates(ref, x, m.skip_indices)
+        logits_ref = D.unetr_head(sd, x, feats, taps, m.feat_size, 96)
+        loss_ref = D.dice_ce_loss(logits_ref, lab)
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        logits = m(x.to(DEV), None)
+        loss = HF.dice_ce(logits, lab.to(DEV))
+    rel = ((logits.float().cpu() - logits_ref).norm() / logits_ref.norm()).item()
+    assert rel < 3e-2, rel
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
