@@ -85,6 +85,41 @@ def test_conv3x3x3_forward_and_gradients(B, X, Y, Z, cin, cout):
 
 
 @pytest.mark.gpu
+def test_conv_strip_kernel_is_bit_identical_to_the_tile_kernel():
+    """the software-pipelined column kernel (single-chunk inputs; picked by size, here forced) against the one-tile-per-workgroup kernel:
+    same MFMA order per output, so bit-identical — for every (Cin, Cout, kernel size) instantiation, ragged extents, fp32 and bf16 output"""
+    import subprocess
+    import sys
+    script = r'''
+import sys, torch
+sys.path.insert(0, "ucf-vit_amd")
+from UCF_VIT._hip import conv, ops
+out = []
+for cin, cout, ks in ((8, 16, 3), (16, 16, 3), (32, 16, 3), (16, 32, 3), (32, 32, 3), (32, 64, 3), (16, 64, 3), (8, 16, 1), (32, 128, 1), (16, 16, 1), (32, 32, 1)):
+    g = torch.Generator().manual_seed(cin * 100 + cout + ks)
+    x = torch.randn(2, 5, 11, 53, cin, generator=g).bfloat16().cuda()
+    w = conv.pack_conv_weight(torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.1).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    out.append(ops.conv3d_fwd(x, w, cout, ksize=ks).float().cpu())
+    out.append(ops.conv3d_fwd(x, w, cout, ksize=ks, bias=b, cout_store=cout - 12, out_dtype=torch.float32).cpu())
+torch.save(out, sys.argv[1])
+'''
+    import os
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("0", "2"):
+            f = os.path.join(d, mode + ".pt")
+            r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, UCFVIT_CONV_STRIP=mode), capture_output=True, text=True,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[mode] = torch.load(f, weights_only=True)
+    assert len(res["0"]) == 22
+    for a, b in zip(res["0"], res["2"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_conv3x3x3_single_channel_input_through_the_padded_operand():
     from UCF_VIT._hip import conv, ops
     g = torch.Generator().manual_seed(3)

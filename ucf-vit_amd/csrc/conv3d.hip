@@ -167,6 +167,128 @@ __global__ __launch_bounds__(CT) void conv_fwd_kernel(const bf16* __restrict__ x
     }
 }
 
+// ---- the same computation for a single-chunk input (Cin <= 32: every layer at the two finest resolutions), software-pipelined: a workgroup
+// walks the whole z extent of its (x, y) tile column.  The weight slab is staged once; the halo of tile z + 1 is fetched into registers while
+// tile z is multiplied out of LDS, so the global-load latency (the dominant cost of the one-tile-per-workgroup kernel at these sizes:
+// ~60..100 MFMAs per wave per tile) is hidden behind the MFMA work.
+template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
+__global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                            OutT* __restrict__ y, ConvGeo g) {
+    typedef CG<CPC, KS> G;
+    constexpr int PAD = G::PAD, HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = 16 + 2 * PAD;
+    constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
+    constexpr int CB = 16 * NB;
+    constexpr int RPW = TX * TY / 4;
+    constexpr int NP = HX * HY * HZ * G::PPV;          // 16-byte pieces of one halo
+    constexpr int NPT = (NP + CT - 1) / CT;            // per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wl = smem + HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    int t = xcd_remap(blockIdx.x, gridDim.x);          // (b, ix, iy) column
+    const int iy = t % g.ty;
+    t /= g.ty;
+    const int ix = t % g.tx, b = t / g.tx;
+    const int x0 = ix * TX, y0 = iy * TY;
+    const int co0 = blockIdx.y * CB;
+    for (int p = tid; p < G::NTS * CB * 4; p += CT) {
+        const int piece = p & 3, row = (p >> 2) % CB, ts = (p >> 2) / CB;
+        *reinterpret_cast<u32x4*>(wl + p * 16) = *reinterpret_cast<const u32x4*>(wp + ((int64_t)ts * g.Cout + co0 + row) * 32 + piece * 8);
+    }
+    // this thread's pieces of a halo: fixed (hx, hy, hz, piece) for every z tile
+    int hoff[NPT], hxy[NPT], hzz[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int p = tid + i * CT;
+        const int hv = p / G::PPV, piece = p % G::PPV;
+        const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+        const int gx = x0 + hx - PAD, gy = y0 + hy - PAD;
+        const bool ok = p < NP && (unsigned)gx < (unsigned)g.X && (unsigned)gy < (unsigned)g.Y;
+        hoff[i] = hv * G::VS + piece * 16;
+        hxy[i] = ok ? (gx * g.Y + gy) : -1;             // row of voxels along z, -1: outside (zero padding) or no piece
+        hzz[i] = ((hz - PAD) & 0xffff) | (piece << 16);
+    }
+    const bf16* xb = x + (int64_t)b * g.X * g.Y * g.Z * g.Cin;
+    u32x4 pre[NPT];
+    auto fetch = [&](int z0) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int gz = z0 + (int)(short)(hzz[i] & 0xffff), piece = hzz[i] >> 16;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (hxy[i] >= 0 && (unsigned)gz < (unsigned)g.Z)
+                v = *reinterpret_cast<const u32x4*>(xb + ((int64_t)hxy[i] * g.Z + gz) * g.Cin + piece * 8);
+            pre[i] = v;
+        }
+    };
+    fetch(0);
+    const bool vec_ok = (g.ldy & 3) == 0;
+    for (int iz = 0; iz < g.tz; ++iz) {
+        const int z0 = iz * 16;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+            if (tid + i * CT < NP) *reinterpret_cast<u32x4*>(halo + hoff[i]) = pre[i];
+        __syncthreads();
+        if (iz + 1 < g.tz) fetch(z0 + 16);              // in flight during the MFMA work below
+        f32x4 acc[RPW][NB];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ts = 0; ts < G::NTS; ++ts) {
+            frag_t a[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const frag_t*>(wl + ((ts * CB + nb * 16 + li) * 64 + lg * 16));
+            int tap, chb;
+            if (CPC == 32) {
+                tap = ts;
+                chb = lg * 16;
+            } else if (CPC == 16) {
+                tap = 2 * ts + (lg >> 1);
+                chb = (lg & 1) * 16;
+            } else {
+                tap = 4 * ts + lg;
+                chb = 0;
+            }
+            if (tap > G::NT - 1) tap = G::NT - 1;
+            const int dx = KS == 3 ? tap / 9 : 0, dy = KS == 3 ? (tap / 3) % 3 : 0, dz = KS == 3 ? tap % 3 : 0;
+            const int boff = ((dx * HY + dy) * HZ + dz + li) * G::VS + chb;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, xl = row / TY, yl = row % TY;
+                const frag_t bf = *reinterpret_cast<const frag_t*>(halo + boff + (xl * HY + yl) * HZ * G::VS);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = mma(a[nb], bf, acc[r][nb]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
+            if (gx < g.X && gy < g.Y && gz < g.Z) {
+                OutT* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.ldy;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c = co0 + nb * 16 + lg * 4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[r][nb][e] + (bias ? bias[c + e] : 0.f);
+                    if (c + 4 <= g.cout_store && vec_ok) {
+                        Vec4<OutT> o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.set(e, v[e]);
+                        *reinterpret_cast<Vec4<OutT>*>(yp + c) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < g.cout_store) yp[c + e] = from_f32<OutT>(v[e]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                // every wave is done with this halo before the next one is written
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
 constexpr int TZW = 32;       // z extent of a weight-gradient tile = one 32-deep contraction step per (x, y) row
 
@@ -195,20 +317,50 @@ __global__ __launch_bounds__(CT) void conv_wgrad_kernel(const bf16* __restrict__
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) acc[k][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int t_lo = blockIdx.x * tiles_per_wg, t_hi = min(g.tiles, t_lo + tiles_per_wg);
-    for (int t = t_lo; t < t_hi; ++t) {
+    // software pipeline over the workgroup's tiles: the dy tile and the x halo of tile t + 1 are fetched into registers while tile t is
+    // multiplied out of LDS.  A thread's pieces have fixed tile-local coordinates: (xl, yl, zl, piece) packed 8 bits each, -1 = no piece.
+    constexpr int DPV = VSD / 16;
+    constexpr int NPD = (TX * TY * TZW * DPV + CT - 1) / CT, NPH = (HX * HY * HZ * G::PPV + CT - 1) / CT;
+    int dyc[NPD], hc[NPH];
+#pragma unroll
+    for (int i = 0; i < NPD; ++i) {
+        const int p = tid + i * CT, v = p / DPV, piece = p % DPV;
+        dyc[i] = p < TX * TY * TZW * DPV ? ((v / (TZW * TY)) | (((v / TZW) % TY) << 8) | ((v % TZW) << 16) | (piece << 24)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NPH; ++i) {
+        const int p = tid + i * CT, hv = p / G::PPV, piece = p % G::PPV;
+        hc[i] = p < HX * HY * HZ * G::PPV ? ((hv / (HZ * HY)) | (((hv / HZ) % HY) << 8) | ((hv % HZ) << 16) | (piece << 24)) : -1;
+    }
+    u32x4 pd[NPD], ph[NPH];
+    auto fetch = [&](int t) {
         int b, ix, iy, iz;
         decode_tile(g, t, b, ix, iy, iz);
         const int x0 = ix * TX, y0 = iy * TY, z0 = iz * TZW;
-        __syncthreads();
-        constexpr int DPV = VSD / 16;
-        for (int p = tid; p < TX * TY * TZW * DPV; p += CT) {
-            const int v = p / DPV, piece = p % DPV;
-            const int zl = v % TZW, yl = (v / TZW) % TY, xl = v / (TZW * TY);
-            *reinterpret_cast<u32x4*>(dyt + v * VSD + piece * 16) =
-                load_voxel(dy, g, b, x0 + xl, y0 + yl, z0 + zl, g.Cout, cob * 16 * MB + piece * 8);
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+            const int c = dyc[i];
+            pd[i] = c < 0 ? u32x4{0u, 0u, 0u, 0u}
+                          : load_voxel(dy, g, b, x0 + (c & 255), y0 + ((c >> 8) & 255), z0 + ((c >> 16) & 255), g.Cout, cob * 16 * MB + (c >> 24) * 8);
         }
-        stage_halo<CPC, PAD, HX, HY, HZ>(halo, x, g, b, x0, y0, z0, cib * CPC, tid);
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) {
+            const int c = hc[i];
+            ph[i] = c < 0 ? u32x4{0u, 0u, 0u, 0u}
+                          : load_voxel(x, g, b, x0 + (c & 255) - PAD, y0 + ((c >> 8) & 255) - PAD, z0 + ((c >> 16) & 255) - PAD, g.Cin,
+                                       cib * CPC + (c >> 24) * 8);
+        }
+    };
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int t = t_lo; t < t_hi; ++t) {
+#pragma unroll
+        for (int i = 0; i < NPD; ++i)
+            if (dyc[i] >= 0) *reinterpret_cast<u32x4*>(dyt + (tid + i * CT) * 16) = pd[i];        // piece p lives at byte 16 p of its image
+#pragma unroll
+        for (int i = 0; i < NPH; ++i)
+            if (hc[i] >= 0) *reinterpret_cast<u32x4*>(halo + (tid + i * CT) * 16) = ph[i];
         __syncthreads();
+        if (t + 1 < t_hi) fetch(t + 1);
         for (int row = (KS == 3 ? 0 : wave); row < TX * TY; row += (KS == 3 ? 1 : 4)) {
             const int xl = row / TY, yl = row % TY;
             frag_t a[MB];
@@ -238,6 +390,7 @@ __global__ __launch_bounds__(CT) void conv_wgrad_kernel(const bf16* __restrict__
                 }
             }
         }
+        __syncthreads();                                // every wave is done with these images before the next tile overwrites them
     }
     // partial [slot][blockIdx.y][tap][16 MB][16 NBK] with slot = the workgroup (KS 3) or (workgroup, wave) (KS 1); D[co = 4 lg + e][ci = li]
     constexpr int PB = 16 * MB * 16 * NBK;
@@ -329,9 +482,52 @@ int launch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGe
     return UCFVIT_OK;
 }
 
+template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
+int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGeo g, hipStream_t s) {
+    typedef CG<CPC, KS> G;
+    g.tx = (g.X + TX - 1) / TX;
+    g.ty = (g.Y + TY - 1) / TY;
+    g.tz = (g.Z + 15) / 16;
+    const int64_t cols = (int64_t)g.B * g.tx * g.ty;
+    UCF_CHECK_ARG(cols < (1ll << 31) && g.Cout / (16 * NB) < 65536, "ucfvit_conv3d_fwd: grid too large");
+    g.tiles = (int)cols;
+    constexpr int SMEM = (TX + 2 * G::PAD) * (TY + 2 * G::PAD) * (16 + 2 * G::PAD) * G::VS + G::NTS * 16 * NB * 64;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT>), dim3((unsigned)cols, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp, bias,
+                       y, g);
+    UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
+    return UCFVIT_OK;
+}
+
+static int strip_mode() {          // UCFVIT_CONV_STRIP: 0 never, 1 (default) when the (x, y) columns fill the chip, 2 whenever the kernel applies (tests)
+    static int flag = -1;
+    if (flag < 0) {
+        const char* e = getenv("UCFVIT_CONV_STRIP");
+        flag = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }
+    return flag;
+}
+
 template <int CPC, int KS, typename OutT>
 int dispatch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, const ConvGeo& g, hipStream_t s) {
     const int nb16 = g.Cout / 16;
+    // single-chunk inputs with at least two z tiles and enough (x, y) columns to fill the chip: the pipelined strip kernel
+    if (g.Cin == CPC && g.Z > 16 && strip_mode()) {
+        const int64_t cols = (int64_t)g.B * ((g.X + 1) / 2) * ((g.Y + 7) / 8);
+        if (strip_mode() == 2 || cols * (nb16 % 4 == 0 ? nb16 / 4 : nb16 % 2 == 0 ? nb16 / 2 : nb16) >= 512) {
+            if (nb16 % 4 == 0) return launch_fwd_strip<CPC, 4, 2, 4, KS, OutT>(x, wp, bias, y, g, s);
+            if (nb16 % 2 == 0) return launch_fwd_strip<CPC, 2, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
+            if constexpr (CPC == 32)
+                return launch_fwd_strip<CPC, 1, 2, 8, KS, OutT>(x, wp, bias, y, g, s);      // the 4 x 8 tile's prefetch would not fit in registers
+            else
+                return launch_fwd_strip<CPC, 1, 4, 8, KS, OutT>(x, wp, bias, y, g, s);
+        }
+    }
     if (nb16 % 4 == 0) return launch_fwd<CPC, 4, 2, 4, KS, OutT>(x, wp, bias, y, g, s);
     if (nb16 % 2 == 0) return launch_fwd<CPC, 2, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
     return launch_fwd<CPC, 1, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
