@@ -345,12 +345,13 @@ int ucfvit_dice_ce_strided(const void* logits, const int64_t* labels, float* los
                            void* workspace, int dtype, void* stream);
 
 /* Channels-last instance norm (+ LeakyReLU, + residual) for the layout of the convolution kernels below: x, res, y [B][S][C] bf16,
- * mean / rstd [B][C] fp32; C a power of two in 8..2048.  Same formulas as ucfvit_instnorm_fwd / _bwd. */
+ * mean / rstd [B][C] fp32; C a power of two in 8..2048.  Same formulas as ucfvit_instnorm_fwd / _bwd.  had_res: the forward pass added a
+ * residual, so the activation mask is read from y; without one sign(y) = sign(x - mean) and y is not read at all (dres requires had_res). */
 int64_t ucfvit_instnorm_cl_workspace(int64_t B, int64_t S, int64_t C);
 int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, float eps,
                            float slope, void* workspace, void* stream);
 int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres, int64_t B,
-                           int64_t S, int64_t C, float slope, void* workspace, void* stream);
+                           int64_t S, int64_t C, float slope, int had_res, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * UNETR convolutional decoder, convolutions.  Reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai's

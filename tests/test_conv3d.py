@@ -222,6 +222,11 @@ def test_instnorm_channels_last_equals_the_row_layout_kernels_and_torch(C, with_
     assert _rel(_ncdhw(xc.grad), xr.grad) < 2e-2
     if with_res:
         assert _rel(_ncdhw(rc.grad), rr.grad) < 1e-2
+        # a residual that needs no gradient: the mask still comes from the saved output (had_res), nothing is written for it
+        xc2 = _cl(x).requires_grad_(True)
+        y2 = conv.instnorm_act_cl(xc2, _cl(res), 1e-5, slope)
+        y2.backward(_cl(dy))
+        assert torch.equal(y2, y) and torch.equal(xc2.grad, xc.grad)
 
 
 @pytest.mark.gpu

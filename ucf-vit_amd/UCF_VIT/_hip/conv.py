@@ -257,7 +257,7 @@ class InstNormActCLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, rstd = ctx.saved_tensors
-        dx, dres = ops.instnorm_cl_bwd(dy.contiguous(), y, x, mean, rstd, ctx.slope, ctx.has_res and ctx.needs_input_grad[1])
+        dx, dres = ops.instnorm_cl_bwd(dy.contiguous(), y, x, mean, rstd, ctx.slope, ctx.has_res and ctx.needs_input_grad[1], had_res=ctx.has_res)
         return dx, dres, None, None
 
 

@@ -706,7 +706,7 @@ def instnorm_cl_fwd(x, res=None, eps=1e-5, slope=0.01):
     return y, mean, rstd
 
 
-def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres):
+def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres, had_res=None):
     L = _l.load()
     _chk_cl(dy, "instnorm_cl_bwd.dy"), _chk_cl(x, "instnorm_cl_bwd.x")
     B, C = x.shape[0], x.shape[-1]
@@ -714,8 +714,9 @@ def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres):
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
+    had_res = want_dres if had_res is None else had_res
     _l.check(L.ucfvit_instnorm_cl_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), B, S, C,
-                                      slope, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd")
+                                      slope, 1 if had_res else 0, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd")
     return dx, dres
 
 

@@ -383,6 +383,9 @@ __global__ __launch_bounds__(NT) void incl_apply(const bf16* __restrict__ x, con
         yb[i] = o;
     }
 }
+// NEED_Y: the activation mask comes from the saved output only when a residual was added before the LeakyReLU; without one
+// sign(y) = sign(x - mean) (rstd > 0), which saves the read of y in both backward passes.
+template <bool NEED_Y>
 __global__ __launch_bounds__(NT) void incl_bwd_partial(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ part,
                                                        int64_t S, int C, int chunks, float slope) {
@@ -401,12 +404,15 @@ __global__ __launch_bounds__(NT) void incl_bwd_partial(const bf16* __restrict__ 
     const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
     const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
     for (int64_t i = vlo + threadIdx.x; i < vhi; i += NT) {
-        const bf16x8 gv = gb[i], yv = yb[i], xv = xb[i];
+        const bf16x8 gv = gb[i], xv = xb[i];
+        bf16x8 yv;
+        if (NEED_Y) yv = yb[i];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float g = (float)gv[e] * ((float)yv[e] > 0.f ? 1.f : slope);
+            const float n = ((float)xv[e] - m[e]) * r[e];
+            const float g = (float)gv[e] * ((NEED_Y ? (float)yv[e] : n) > 0.f ? 1.f : slope);
             s1[e] += g;
-            s2[e] += g * ((float)xv[e] - m[e]) * r[e];
+            s2[e] += g * n;
         }
     }
     cl_fold(s1, s2, red, part + (b * chunks + blockIdx.x) * 2 * C, C, cv);
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(64) void incl_bwd_final(const float* __restrict__ p
         m2[blockIdx.x] = (float)(s2 / (double)S);
     }
 }
-template <bool RES>
+template <bool RES, bool WRES>
 __global__ __launch_bounds__(NT) void incl_bwd_apply(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m1,
                                                      const float* __restrict__ m2, bf16* __restrict__ dx, bf16* __restrict__ dres, int64_t S, int C,
@@ -452,17 +458,18 @@ __global__ __launch_bounds__(NT) void incl_bwd_apply(const bf16* __restrict__ dy
     bf16x8* dxb = reinterpret_cast<bf16x8*>(dx + b * S * C);
     bf16x8* drb = reinterpret_cast<bf16x8*>(dres + b * S * C);
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
-        const bf16x8 gv = gb[i], yv = yb[i], xv = xb[i];
-        bf16x8 ox, orr;
+        const bf16x8 gv = gb[i], xv = xb[i];
+        bf16x8 yv, ox, orr;
+        if (RES) yv = yb[i];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float dn = (float)gv[e] * ((float)yv[e] > 0.f ? 1.f : slope);
             const float n = ((float)xv[e] - m[e]) * r[e];
+            const float dn = (float)gv[e] * ((RES ? (float)yv[e] : n) > 0.f ? 1.f : slope);
             ox[e] = (bf16)(r[e] * (dn - a1[e] - n * a2[e]));
-            if (RES) orr[e] = (bf16)dn;
+            if (WRES) orr[e] = (bf16)dn;
         }
         dxb[i] = ox;
-        if (RES) drb[i] = orr;
+        if (WRES) drb[i] = orr;
     }
 }
 int cl_chunks_of(int64_t S, int64_t C) { return (int)((S * (C / 8) + CLV - 1) / CLV); }
@@ -611,7 +618,7 @@ extern "C" int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, f
     return UCFVIT_OK;
 }
 extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres,
-                                      int64_t B, int64_t S, int64_t C, float slope, void* workspace, void* stream) {
+                                      int64_t B, int64_t S, int64_t C, float slope, int had_res, void* workspace, void* stream) {
     if (int rc = incl_check("ucfvit_instnorm_cl_bwd", x, B, S, C)) return rc;
     UCF_CHECK_ARG(dy && y && mean && rstd && dx && workspace, "ucfvit_instnorm_cl_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -619,16 +626,25 @@ extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void*
     float* part = (float*)workspace;
     float* m1 = part + B * ch * 2 * C;
     float* m2 = m1 + B * C;
-    hipLaunchKernelGGL(incl_bwd_partial, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, part,
-                       S, (int)C, ch, slope);
+    UCF_CHECK_ARG(had_res || !dres, "ucfvit_instnorm_cl_bwd: dres without a residual in the forward pass");
+    if (had_res)
+        hipLaunchKernelGGL(incl_bwd_partial<true>, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
+                           part, S, (int)C, ch, slope);
+    else
+        hipLaunchKernelGGL(incl_bwd_partial<false>, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
+                           part, S, (int)C, ch, slope);
     hipLaunchKernelGGL(incl_bwd_final, dim3((unsigned)(B * C)), dim3(64), 0, s, part, m1, m2, S, (int)C, ch);
     const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+#define INCL_BWD_APPLY(R_, W_)                                                                                                                  \
+    hipLaunchKernelGGL((incl_bwd_apply<R_, W_>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2, (bf16*)dx, \
+                       (bf16*)(dres ? dres : dx), S, (int)C, slope)
     if (dres)
-        hipLaunchKernelGGL((incl_bwd_apply<true>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2,
-                           (bf16*)dx, (bf16*)dres, S, (int)C, slope);
+        INCL_BWD_APPLY(true, true);
+    else if (had_res)
+        INCL_BWD_APPLY(true, false);
     else
-        hipLaunchKernelGGL((incl_bwd_apply<false>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2,
-                           (bf16*)dx, (bf16*)dx, S, (int)C, slope);
+        INCL_BWD_APPLY(false, false);
+#undef INCL_BWD_APPLY
     UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd");
     return UCFVIT_OK;
 }
