@@ -166,6 +166,24 @@ class UNETR(_TPMixin, _S.UNETR):
         return intermediates if intermediates_only else (self.norm(x), intermediates)
 
 
+    def forward(self, x, variables, seq_ps=None, x_seq=None):
+        """sequence-parallel whole model: the encoder runs on token shards (every rank receives the whole volume and embeds its slab), the
+        shards of the final features and of the taps are all-gathered, and the convolutional decoder runs replicated on every rank of the
+        group (its gradients are rank-identical; the encoder's are sums over the shards, as in forward_intermediates)"""
+        if self.seq_par_size <= 1:
+            return super().forward(x, variables, seq_ps, x_seq)
+        assert self.skip_connection and not self.linear_decoder, "sequence parallelism is wired for the skip-connection decoder"
+        from .seq_parallel import gather_tokens_autograd
+        feats, taps = self.forward_intermediates(x, variables, seq_ps, indices=self.skip_indices)
+        feats = gather_tokens_autograd(feats, self._spg)
+        taps = [gather_tokens_autograd(t, self._spg) for t in taps]
+        if self.hip_decoder():
+            from UCF_VIT._hip import ops as _ops
+            enc1 = self.encoder1.forward_cl(_ops.pad_channels8(x.float().contiguous()))
+            return self._unetr_head_cl(self.pool(feats), taps, enc1)
+        return self.forward_head(feats, taps, self.encoder1(x))
+
+
 class SAP(_TPMixin, _S.SAP):
     """SAP with the Hybrid-OP arguments (reference fsdp/arch.py:1311-1338: tensor-parallel Blocks inside the broadcast bracket)"""
 

@@ -314,3 +314,24 @@ def gather_tokens(x_local, spg):
     else:
         dist.all_gather(parts, x_local.contiguous(), group=spg.sp_group)
     return torch.cat(parts, dim=1)
+
+
+class GatherTokensFn(torch.autograd.Function):
+    """differentiable gather_tokens for a consumer that every rank of the group runs IDENTICALLY on the gathered sequence (the UNETR
+    convolutional decoder, replicated): forward all-gathers the shards, backward hands each rank the slice of the (rank-identical) gradient
+    that belongs to its shard — no reduction, the replicas count as one consumer"""
+
+    @staticmethod
+    def forward(ctx, x_local, spg):
+        ctx.spg = spg
+        ctx.n = x_local.shape[1]
+        return gather_tokens(x_local, spg)
+
+    @staticmethod
+    def backward(ctx, g):
+        lo = ctx.spg.rank * ctx.n
+        return g[:, lo:lo + ctx.n].contiguous(), None
+
+
+def gather_tokens_autograd(x_local, spg):
+    return GatherTokensFn.apply(x_local, spg)
