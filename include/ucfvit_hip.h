@@ -346,12 +346,13 @@ int ucfvit_dice_ce_strided(const void* logits, const int64_t* labels, float* los
 
 /* Channels-last instance norm (+ LeakyReLU, + residual) for the layout of the convolution kernels below: x, res, y [B][S][C] bf16,
  * mean / rstd [B][C] fp32; C a power of two in 8..2048.  Same formulas as ucfvit_instnorm_fwd / _bwd.  had_res: the forward pass added a
- * residual, so the activation mask is read from y; without one sign(y) = sign(x - mean) and y is not read at all (dres requires had_res). */
+ * residual, so the activation mask is read from y; without one sign(y) = sign(x - mean) and y is not read at all (dres requires had_res).
+ * ld_dy: voxel-row stride of dy in elements (C for a dense tensor; larger when dy is a channel slice of a concatenation's gradient). */
 int64_t ucfvit_instnorm_cl_workspace(int64_t B, int64_t S, int64_t C);
 int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, float eps,
                            float slope, void* workspace, void* stream);
 int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres, int64_t B,
-                           int64_t S, int64_t C, float slope, int had_res, void* workspace, void* stream);
+                           int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * UNETR convolutional decoder, convolutions.  Reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai's
@@ -372,7 +373,10 @@ int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const f
  *   CPC = 8 columns 8..15 are scratch).  workspace: ucfvit_conv3d_wgrad_workspace bytes (per-workgroup partials, folded in a fixed order:
  *   deterministic).
  * ucfvit_depth_to_space2: the transposed convolution is the GEMM x[V][Cin] * w[Cin][8 Cout] followed by this shuffle of
- *   cols [B Xi Yi Zi][(dx, dy, dz)][C] into out [B][2 Xi][2 Yi][2 Zi][C] (to_space = 1) — or its inverse for the backward pass (0).
+ *   cols [B Xi Yi Zi][(dx, dy, dz)][C] into out [B][2 Xi][2 Yi][2 Zi][C] (to_space = 1) — or its inverse for the backward pass (0).  The
+ *   space tensor may be a channel slice of a wider channels-last buffer (voxel-row stride ld_space elements): the up-sampled map is written
+ *   straight into the concatenation the next block reads; with `skip` (dense [..][Cs], to_space = 1) the skip connection is copied behind it
+ *   in the same pass, so the concatenation is written as whole rows.
  * ucfvit_pad_channels8: fp32 N C D H W input [B][C][S] with C <= 8 -> bf16 channels-last [B][S][8] (channels C..7 zero): the input volume as
  *   an operand of the kernels above.
  * ------------------------------------------------------------------------------------------------------ */
@@ -382,7 +386,8 @@ int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout, int ksize);
 int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize);
 int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y, int64_t Z,
                         int64_t Cin, int64_t Cout, int ksize, void* stream);
-int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int to_space, void* stream);
+int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int64_t ld_space, int to_space,
+                           const void* skip, int64_t Cs, void* stream);
 int ucfvit_pad_channels8(const float* src, void* dst, int64_t B, int64_t C, int64_t S, void* stream);
 
 #ifdef __cplusplus

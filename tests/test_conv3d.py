@@ -162,6 +162,29 @@ def test_tconv2x2x2_forward_and_gradients(B, X, Y, Z, cin, cout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,cs", [(32, 16, 16), (128, 64, 64), (64, 32, 32)])
+def test_tconv_with_skip_writes_the_concatenation_in_place(cin, cout, cs):
+    """tconv2x2x2(x, w, skip) == cat(tconv2x2x2(x, w), skip) bit for bit, and so are all three gradients when the consumer is a normalisation
+    (whose backward reads the skip half of the concatenation's gradient as a strided slice)"""
+    from UCF_VIT._hip import conv
+    g = torch.Generator().manual_seed(cin + cs)
+    x = torch.randn(2, 3, 4, 5, cin, generator=g).bfloat16().cuda()
+    w = (torch.randn(cin, cout, 2, 2, 2, generator=g) * cin ** -0.5).cuda()
+    skip_pre = torch.randn(2, 6, 8, 10, cs, generator=g).bfloat16().cuda()
+    dcat = torch.randn(2, 6, 8, 10, cout + cs, generator=g).bfloat16().cuda()
+    res = []
+    for fused in (False, True):
+        xc, wp, sp = x.clone().requires_grad_(True), w.clone().requires_grad_(True), skip_pre.clone().requires_grad_(True)
+        skip = conv.instnorm_act_cl(sp, None, 1e-5, 0.01)                     # the skip is a residual block's output: a normalisation
+        cat = conv.tconv2x2x2(xc, wp, skip) if fused else torch.cat((conv.tconv2x2x2(xc, wp), skip), dim=-1)
+        assert cat.shape == (2, 6, 8, 10, cout + cs) and cat.is_contiguous()
+        cat.backward(dcat)
+        res.append((cat.detach(), xc.grad, wp.grad, sp.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_depth_to_space_round_trip_is_exact():
     from UCF_VIT._hip import ops
     cols = torch.randn(2 * 3 * 4 * 5, 8 * 16).bfloat16().cuda()

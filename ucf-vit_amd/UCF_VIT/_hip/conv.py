@@ -150,10 +150,13 @@ class Conv3x3x3Fn(torch.autograd.Function):
 
 class TConv2x2x2Fn(torch.autograd.Function):
     """ConvTranspose3d(k=2, s=2): out[2v + d][co] = sum_ci x[v][ci] w[ci][co][d] = a pointwise layer to 8 Cout channels + depth-to-space.
-    Large channel counts (the 768-wide token maps) use the tiled GEMM; small ones the 1x1x1 convolution kernel."""
+    Large channel counts (the 768-wide token maps) use the tiled GEMM; small ones the 1x1x1 convolution kernel.
+    With `skip` ([B, 2X, 2Y, 2Z, Cs]) the result is the channel concatenation (out, skip) of monai's UnetrUpBlock: the depth-to-space pass
+    writes the up-sampled map straight into the first Cout channels of the concatenation, and the backward pass reads the two halves of the
+    concatenation's gradient in place (no torch.cat / slice copies of the largest tensors of the decoder)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, skip):
         cin, cout = w.shape[0], w.shape[1]
         if tuple(w.shape[2:]) != (2, 2, 2) or x.shape[-1] != cin:
             raise ValueError("tconv2x2x2: weight must be [Cin, Cout, 2, 2, 2] with Cin = the input's channels")
@@ -169,13 +172,26 @@ class TConv2x2x2Fn(torch.autograd.Function):
             cols = ops.linear_fwd(x.reshape(-1, cin), w2)
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(w.shape)
-        return ops.depth_to_space2(cols.view(-1, 8 * cout), B, X, Y, Z, cout)
+        ctx.cs = 0
+        if skip is None:
+            return ops.depth_to_space2(cols.view(-1, 8 * cout), B, X, Y, Z, cout)
+        if tuple(skip.shape[:4]) != (B, 2 * X, 2 * Y, 2 * Z) or skip.dtype != torch.bfloat16 or cout % 8 or skip.shape[-1] % 8:
+            raise ValueError("tconv2x2x2: skip must be a channels-last bf16 map of the up-sampled extent")
+        ctx.cs = skip.shape[-1]
+        cat = torch.empty((B, 2 * X, 2 * Y, 2 * Z, cout + ctx.cs), dtype=torch.bfloat16, device=x.device)
+        ops.depth_to_space2(cols.view(-1, 8 * cout), B, X, Y, Z, cout, out=cat[..., :cout], skip=skip.contiguous())   # whole rows in one pass
+        return cat
 
     @staticmethod
     def backward(ctx, dy):
         x, w2 = ctx.saved_tensors
         cin, cout = ctx.wshape[0], ctx.wshape[1]
-        dcols = ops.space_to_depth2(dy.contiguous())
+        dskip = None
+        if ctx.cs:
+            if ctx.needs_input_grad[2]:
+                dskip = dy[..., cout:]                      # a view: the consumer (normalisation backward) reads the slice in place
+            dy = dy[..., :cout]
+        dcols = ops.space_to_depth2(dy)
         dx = dw = None
         if ctx.small:
             dcols = dcols.view(tuple(x.shape[:-1]) + (8 * cout,))
@@ -190,7 +206,7 @@ class TConv2x2x2Fn(torch.autograd.Function):
                 dw2 = ops.linear_wgrad(dcols, x.reshape(-1, cin))                                            # [8 Cout, Cin] fp32
         if ctx.needs_input_grad[1]:
             dw = dw2.reshape(2, 2, 2, cout, cin).permute(4, 3, 0, 1, 2).contiguous()
-        return dx, dw
+        return dx, dw, dskip
 
 
 class Conv1x1x1Fn(torch.autograd.Function):
@@ -257,7 +273,7 @@ class InstNormActCLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, rstd = ctx.saved_tensors
-        dx, dres = ops.instnorm_cl_bwd(dy.contiguous(), y, x, mean, rstd, ctx.slope, ctx.has_res and ctx.needs_input_grad[1], had_res=ctx.has_res)
+        dx, dres = ops.instnorm_cl_bwd(dy, y, x, mean, rstd, ctx.slope, ctx.has_res and ctx.needs_input_grad[1], had_res=ctx.has_res)
         return dx, dres, None, None
 
 
@@ -265,8 +281,9 @@ def conv3x3x3(x, w):
     return Conv3x3x3Fn.apply(x, w)
 
 
-def tconv2x2x2(x, w):
-    return TConv2x2x2Fn.apply(x, w)
+def tconv2x2x2(x, w, skip=None):
+    """skip given: returns the channel concatenation (transposed convolution, skip) — see TConv2x2x2Fn"""
+    return TConv2x2x2Fn.apply(x, w, skip)
 
 
 def conv1x1x1(x, w, b=None, out_fp32=False):

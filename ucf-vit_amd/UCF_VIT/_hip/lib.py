@@ -79,12 +79,12 @@ SIGNATURES = {
     "ucfvit_dice_ce_strided": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _F, _F, _P, _I, _P]),
     "ucfvit_instnorm_cl_workspace": (_I64, [_I64, _I64, _I64]),
     "ucfvit_instnorm_cl_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P]),
-    "ucfvit_instnorm_cl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _I, _P, _P]),
+    "ucfvit_instnorm_cl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P, _P]),
     "ucfvit_conv3d_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I64, _I64, _I, _P]),
     "ucfvit_conv3d_wgrad_size": (_I64, [_I64, _I64, _I]),
     "ucfvit_conv3d_wgrad_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64, _I]),
     "ucfvit_conv3d_wgrad": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P]),
-    "ucfvit_depth_to_space2": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "ucfvit_depth_to_space2": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P, _I64, _P]),
     "ucfvit_pad_channels8": (c_int, [_P, _P, _I64, _I64, _I64, _P]),
     "ucfvit_cross_entropy": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P]),
     "ucfvit_mae_mask": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),

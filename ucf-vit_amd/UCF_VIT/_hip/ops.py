@@ -651,27 +651,59 @@ def conv3d_wgrad(x, dy, ksize=3):
     return dw
 
 
-def depth_to_space2(cols, B, Xi, Yi, Zi, C):
-    """cols [B Xi Yi Zi, 8 C] (column blocks (dx, dy, dz)) -> [B, 2Xi, 2Yi, 2Zi, C]"""
+def cl_row_stride(t):
+    """voxel-row stride (elements) of a channels-last bf16 tensor [B, X, Y, Z, C] that is dense or a channel slice of a dense
+    [B, X, Y, Z, ld] buffer (what torch.cat's backward and a pre-allocated concatenation hand around); None if it is neither"""
+    if t.dim() != 5 or t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(-1) != 1:
+        return None
+    ld = t.stride(-2)
+    if ld < t.shape[-1] or ld % 8 or t.data_ptr() % 16:
+        return None
+    exp = ld
+    for d in (3, 2, 1):
+        if t.stride(d) != exp and t.shape[d] != 1:
+            return None
+        exp *= t.shape[d]
+    if t.stride(0) != exp and t.shape[0] != 1:
+        return None
+    return ld
+
+
+def depth_to_space2(cols, B, Xi, Yi, Zi, C, out=None, skip=None):
+    """cols [B Xi Yi Zi, 8 C] (column blocks (dx, dy, dz)) -> [B, 2Xi, 2Yi, 2Zi, C]; `out` may be a channel slice of a wider channels-last
+    buffer; with `skip` (dense [B, 2Xi, 2Yi, 2Zi, Cs]) the buffer behind `out` must be C + Cs wide and receives the skip behind the C channels"""
     L = _l.load()
     _chk(cols, "depth_to_space2.cols")
     if cols.dtype != torch.bfloat16 or cols.numel() != B * Xi * Yi * Zi * 8 * C:
         raise ValueError("depth_to_space2: bad operand")
-    out = torch.empty((B, 2 * Xi, 2 * Yi, 2 * Zi, C), dtype=torch.bfloat16, device=cols.device)
-    _l.check(L.ucfvit_depth_to_space2(cols.data_ptr(), out.data_ptr(), B, Xi, Yi, Zi, C, 1, _stream()), "ucfvit_depth_to_space2")
+    if out is None:
+        out = torch.empty((B, 2 * Xi, 2 * Yi, 2 * Zi, C), dtype=torch.bfloat16, device=cols.device)
+    ld = cl_row_stride(out)
+    if ld is None or tuple(out.shape) != (B, 2 * Xi, 2 * Yi, 2 * Zi, C):
+        raise ValueError("depth_to_space2: out must be [B, 2Xi, 2Yi, 2Zi, C], dense or a channel slice of a dense channels-last buffer")
+    cs = 0
+    if skip is not None:
+        _chk_cl(skip, "depth_to_space2.skip")
+        cs = skip.shape[-1]
+        if tuple(skip.shape[:4]) != tuple(out.shape[:4]) or ld < C + cs:
+            raise ValueError("depth_to_space2: skip must cover the output's voxels and fit behind it in the buffer")
+    _l.check(L.ucfvit_depth_to_space2(cols.data_ptr(), out.data_ptr(), B, Xi, Yi, Zi, C, ld, 1, _p(skip), cs, _stream()), "ucfvit_depth_to_space2")
     return out
 
 
 def space_to_depth2(y):
-    """[B, 2Xi, 2Yi, 2Zi, C] -> [B Xi Yi Zi, 8 C]"""
+    """[B, 2Xi, 2Yi, 2Zi, C] (dense or a channel slice of a dense channels-last buffer) -> [B Xi Yi Zi, 8 C]"""
     L = _l.load()
-    _chk_cl(y, "space_to_depth2.y")
+    ld = cl_row_stride(y)
+    if ld is None:
+        y = _chk_cl(y.contiguous(), "space_to_depth2.y")
+        ld = y.shape[-1]
     B, X2, Y2, Z2, C = y.shape
     if X2 % 2 or Y2 % 2 or Z2 % 2:
         raise ValueError("space_to_depth2: extents must be even")
     Xi, Yi, Zi = X2 // 2, Y2 // 2, Z2 // 2
     cols = torch.empty((B * Xi * Yi * Zi, 8 * C), dtype=torch.bfloat16, device=y.device)
-    _l.check(L.ucfvit_depth_to_space2(y.data_ptr(), cols.data_ptr(), B, Xi, Yi, Zi, C, 0, _stream()), "ucfvit_depth_to_space2")
+    _l.check(L.ucfvit_depth_to_space2(y.data_ptr(), cols.data_ptr(), B, Xi, Yi, Zi, C, ld, 0, None, 0, _stream()), "ucfvit_depth_to_space2")
     return cols
 
 
@@ -707,8 +739,13 @@ def instnorm_cl_fwd(x, res=None, eps=1e-5, slope=0.01):
 
 
 def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres, had_res=None):
+    """dy may be a channel slice of a wider channels-last gradient (the skip half of a concatenation's gradient): read in place"""
     L = _l.load()
-    _chk_cl(dy, "instnorm_cl_bwd.dy"), _chk_cl(x, "instnorm_cl_bwd.x")
+    _chk_cl(x, "instnorm_cl_bwd.x")
+    ld = cl_row_stride(dy)
+    if ld is None or dy.shape != x.shape:
+        dy = _chk_cl(dy.contiguous(), "instnorm_cl_bwd.dy")
+        ld = dy.shape[-1]
     B, C = x.shape[0], x.shape[-1]
     S = x.numel() // (B * C)
     dx = torch.empty_like(x)
@@ -716,7 +753,7 @@ def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres, had_res=None):
     ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
     had_res = want_dres if had_res is None else had_res
     _l.check(L.ucfvit_instnorm_cl_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), B, S, C,
-                                      slope, 1 if had_res else 0, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd")
+                                      ld, slope, 1 if had_res else 0, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd")
     return dx, dres
 
 

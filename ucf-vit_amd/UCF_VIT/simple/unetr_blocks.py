@@ -111,8 +111,7 @@ class UnetrUpBlock(nn.Module):
         return self.conv_block(torch.cat((out, skip), dim=1))
 
     def forward_cl(self, inp, skip):
-        out = HC.tconv2x2x2(inp, self.transp_conv.conv.weight)
-        return self.conv_block.forward_cl(torch.cat((out, skip), dim=-1))
+        return self.conv_block.forward_cl(HC.tconv2x2x2(inp, self.transp_conv.conv.weight, skip))      # (up-sampled, skip) concatenated in place
 
 
 class UnetOutBlock(nn.Module):

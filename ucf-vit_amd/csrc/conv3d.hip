@@ -412,16 +412,25 @@ __global__ __launch_bounds__(CT) void conv_wgrad_kernel(const bf16* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------------- data movers
 // depth-to-space of the transposed convolution's GEMM output: cols [B Xi Yi Zi][8 C] with the 8 = (dx, dy, dz) -> out [B][2Xi][2Yi][2Zi][C]
-// (to_space = 1), or the inverse gather for the backward pass (to_space = 0).  16 bytes per thread step; C % 8 == 0.
+// (to_space = 1), or the inverse gather for the backward pass (to_space = 0).  16 bytes per thread step; C % 8 == 0.  The space tensor may be
+// a channel slice of a wider channels-last buffer (row stride lds8 sixteen-byte units): the up-sampled map is written straight into the
+// first half of the concatenation the next residual block reads, and its gradient is gathered straight out of that block's input gradient.
 __global__ __launch_bounds__(CT) void d2s_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int Xi, int Yi, int Zi, int C,
-                                                 int to_space) {
-    const int cv = C / 8;
-    const int64_t total = (int64_t)B * Xi * Yi * Zi * 8 * cv;
+                                                 int to_space, int64_t lds8, const bf16* __restrict__ skip, int Cs) {
+    // the thread index walks the vectors of the space-side ROW that this launch touches: C / 8 of the up-sampled map, then (to_space with a
+    // skip) Cs / 8 of the skip connection, so a whole row of the concatenation is written by consecutive lanes (full cache lines)
+    const int cv = C / 8, cvt = cv + (skip ? Cs / 8 : 0);
+    const int64_t total = (int64_t)B * Xi * Yi * Zi * 8 * cvt;
     for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < total; i += (int64_t)gridDim.x * CT) {
-        // i walks the SPACE tensor [b][xo][yo][zo][cv]
         int64_t r = i;
-        const int c = (int)(r % cv);
-        r /= cv;
+        const int c = (int)(r % cvt);
+        r /= cvt;
+        const int64_t vox = r;                                  // linear voxel index of the space tensor
+        const int64_t k = vox * lds8 + c;
+        if (c >= cv) {                                          // skip half of the concatenation
+            reinterpret_cast<u32x4*>(dst)[k] = reinterpret_cast<const u32x4*>(skip)[vox * (Cs / 8) + (c - cv)];
+            continue;
+        }
         const int zo = (int)(r % (2 * Zi));
         r /= 2 * Zi;
         const int yo = (int)(r % (2 * Yi));
@@ -431,9 +440,9 @@ __global__ __launch_bounds__(CT) void d2s_kernel(const bf16* __restrict__ src, b
         const int64_t vin = ((b * Xi + (xo >> 1)) * Yi + (yo >> 1)) * Zi + (zo >> 1);
         const int64_t j = (vin * 8 + ((xo & 1) * 4 + (yo & 1) * 2 + (zo & 1))) * cv + c;
         if (to_space)
-            reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[j];
+            reinterpret_cast<u32x4*>(dst)[k] = reinterpret_cast<const u32x4*>(src)[j];
         else
-            reinterpret_cast<u32x4*>(dst)[j] = reinterpret_cast<const u32x4*>(src)[i];
+            reinterpret_cast<u32x4*>(dst)[j] = reinterpret_cast<const u32x4*>(src)[k];
     }
 }
 
@@ -646,16 +655,21 @@ extern "C" int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_pack
     return UCFVIT_OK;
 }
 
-// to_space = 1: cols [B Xi Yi Zi][8 C] -> out [B][2Xi][2Yi][2Zi][C];  to_space = 0: the inverse.  bf16, C % 8 == 0.
-extern "C" int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int to_space,
-                                      void* stream) {
+// to_space = 1: cols [B Xi Yi Zi][8 C] -> space[voxel * ld_space + c] over [B][2Xi][2Yi][2Zi] voxels;  to_space = 0: the inverse.  bf16, C % 8 == 0,
+// ld_space % 8 == 0 (ld_space = C: a dense tensor; larger: a channel slice of a wider channels-last buffer, pointer at the slice's first channel).
+// skip (to_space = 1 only, may be NULL): dense [B][2Xi][2Yi][2Zi][Cs] map copied behind the C channels of every voxel row in the same pass
+// (ld_space >= C + Cs): the concatenation (up-sampled, skip) of UnetrUpBlock written as whole rows.
+extern "C" int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int64_t ld_space,
+                                      int to_space, const void* skip, int64_t Cs, void* stream) {
     UCF_CHECK_ARG(src && dst && B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && C > 0 && C % 8 == 0, "ucfvit_depth_to_space2: bad arguments");
+    UCF_CHECK_ARG(ld_space >= C && ld_space % 8 == 0, "ucfvit_depth_to_space2: ld_space must be a multiple of 8 and >= C");
     UCF_CHECK_ARG(ucf_is_aligned16(src) && ucf_is_aligned16(dst), "ucfvit_depth_to_space2: operands must be 16-byte aligned");
-    const int64_t total = B * Xi * Yi * Zi * C;       // 16-byte pieces: 8 sub-voxels x C / 8
+    if (skip) UCF_CHECK_ARG(to_space == 1 && Cs > 0 && Cs % 8 == 0 && ld_space >= C + Cs && ucf_is_aligned16(skip), "ucfvit_depth_to_space2: bad skip operand");
+    const int64_t total = B * Xi * Yi * Zi * (C + (skip ? Cs : 0));       // 16-byte pieces
     int64_t blocks = (total + CT - 1) / CT;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(d2s_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, (int)B, (int)Xi,
-                       (int)Yi, (int)Zi, (int)C, to_space);
+                       (int)Yi, (int)Zi, (int)C, to_space, ld_space / 8, (const bf16*)skip, (int)Cs);
     UCF_LAUNCH_CHECK("ucfvit_depth_to_space2");
     return UCFVIT_OK;
 }

@@ -388,10 +388,10 @@ __global__ __launch_bounds__(NT) void incl_apply(const bf16* __restrict__ x, con
 template <bool NEED_Y>
 __global__ __launch_bounds__(NT) void incl_bwd_partial(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ part,
-                                                       int64_t S, int C, int chunks, float slope) {
+                                                       int64_t S, int C, int chunks, float slope, int64_t ldg8) {
     __shared__ float red[NT][17];
     const int64_t b = blockIdx.y;
-    const int cv = C >> 3, cg = threadIdx.x % cv;
+    const int cv = C >> 3, cg = threadIdx.x % cv, cvs = __builtin_ctz(cv);
     float m[8], r[8], s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -400,11 +400,11 @@ __global__ __launch_bounds__(NT) void incl_bwd_partial(const bf16* __restrict__ 
         s1[e] = s2[e] = 0.f;
     }
     const int64_t nvec = S * cv, vlo = (int64_t)blockIdx.x * CLV, vhi = min(nvec, vlo + CLV);
-    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy + b * S * C);
+    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy) + b * S * ldg8;       // dy rows may be ldg8 16-byte units apart (a channel slice)
     const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
     const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
     for (int64_t i = vlo + threadIdx.x; i < vhi; i += NT) {
-        const bf16x8 gv = gb[i], xv = xb[i];
+        const bf16x8 gv = gb[(i >> cvs) * ldg8 + cg], xv = xb[i];
         bf16x8 yv;
         if (NEED_Y) yv = yb[i];
 #pragma unroll
@@ -440,9 +440,9 @@ template <bool RES, bool WRES>
 __global__ __launch_bounds__(NT) void incl_bwd_apply(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m1,
                                                      const float* __restrict__ m2, bf16* __restrict__ dx, bf16* __restrict__ dres, int64_t S, int C,
-                                                     float slope) {
+                                                     float slope, int64_t ldg8) {
     const int64_t b = blockIdx.y;
-    const int cv = C >> 3, cg = threadIdx.x % cv;
+    const int cv = C >> 3, cg = threadIdx.x % cv, cvs = __builtin_ctz(cv);
     float m[8], r[8], a1[8], a2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -452,13 +452,13 @@ __global__ __launch_bounds__(NT) void incl_bwd_apply(const bf16* __restrict__ dy
         a2[e] = m2[b * C + cg * 8 + e];
     }
     const int64_t nvec = S * cv;
-    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy + b * S * C);
+    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy) + b * S * ldg8;
     const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
     const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
     bf16x8* dxb = reinterpret_cast<bf16x8*>(dx + b * S * C);
     bf16x8* drb = reinterpret_cast<bf16x8*>(dres + b * S * C);
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
-        const bf16x8 gv = gb[i], xv = xb[i];
+        const bf16x8 gv = gb[(i >> cvs) * ldg8 + cg], xv = xb[i];
         bf16x8 yv, ox, orr;
         if (RES) yv = yb[i];
 #pragma unroll
@@ -618,8 +618,10 @@ extern "C" int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, f
     return UCFVIT_OK;
 }
 extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres,
-                                      int64_t B, int64_t S, int64_t C, float slope, int had_res, void* workspace, void* stream) {
+                                      int64_t B, int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* workspace, void* stream) {
     if (int rc = incl_check("ucfvit_instnorm_cl_bwd", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(ld_dy >= C && ld_dy % 8 == 0 && ucf_is_aligned16(dy), "ucfvit_instnorm_cl_bwd: ld_dy must be a multiple of 8 and >= C");
+    const int64_t ldg8 = ld_dy / 8;
     UCF_CHECK_ARG(dy && y && mean && rstd && dx && workspace, "ucfvit_instnorm_cl_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int ch = cl_chunks_of(S, C);
@@ -629,15 +631,15 @@ extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void*
     UCF_CHECK_ARG(had_res || !dres, "ucfvit_instnorm_cl_bwd: dres without a residual in the forward pass");
     if (had_res)
         hipLaunchKernelGGL(incl_bwd_partial<true>, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
-                           part, S, (int)C, ch, slope);
+                           part, S, (int)C, ch, slope, ldg8);
     else
         hipLaunchKernelGGL(incl_bwd_partial<false>, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
-                           part, S, (int)C, ch, slope);
+                           part, S, (int)C, ch, slope, ldg8);
     hipLaunchKernelGGL(incl_bwd_final, dim3((unsigned)(B * C)), dim3(64), 0, s, part, m1, m2, S, (int)C, ch);
     const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
 #define INCL_BWD_APPLY(R_, W_)                                                                                                                  \
     hipLaunchKernelGGL((incl_bwd_apply<R_, W_>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2, (bf16*)dx, \
-                       (bf16*)(dres ? dres : dx), S, (int)C, slope)
+                       (bf16*)(dres ? dres : dx), S, (int)C, slope, ldg8)
     if (dres)
         INCL_BWD_APPLY(true, true);
     else if (had_res)
