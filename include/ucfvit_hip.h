@@ -364,7 +364,8 @@ int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const f
  * ucfvit_conv3d_fwd: y[v ldy + co] = bias[co] + sum_{tap, ci} w[co][ci][tap] x[v + tap - pad][ci] for co < cout_store (zero outside the
  *   volume; ksize 3 with padding 1, or ksize 1 = a pointwise layer over tall-skinny voxel rows), fp32 accumulation on MFMA, output bf16 or
  *   fp32 (out_dtype).  Cin in {8, 16, 32 k}, Cout = 16 k = the rows of w_packed; cout_store <= Cout channels are written with row stride
- *   ldy (a 4-class head writes [V][4] from a 16-row weight block); bias fp32 [Cout] or NULL.
+ *   ldy (a 4-class head writes [V][4] from a 16-row weight block); bias fp32 [Cout] or NULL; accumulate: y += result (the second of two
+ *   data gradients that flow into the same input, e.g. a residual block's 3x3x3 and 1x1x1 branches).
  *   w_packed (bf16) holds the weights per 32-wide contraction step: with CPC = min(Cin, 32), TPS = 32 / CPC taps per step and
  *   NTS = ceil(ksize^3 / TPS) steps per channel chunk, w_packed[cc][ts][co][kk] = w[co][cc CPC + kk % CPC][tap] for tap = ts TPS + kk / CPC
  *   (zero when tap >= ksize^3); tap = (dx 3 + dy) 3 + dz.  The data gradient is the same call on dy with the flipped, transposed weights.
@@ -381,7 +382,7 @@ int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const f
  *   an operand of the kernels above.
  * ------------------------------------------------------------------------------------------------------ */
 int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
-                      int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, void* stream);
+                      int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate, void* stream);
 int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout, int ksize);
 int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize);
 int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y, int64_t Z,

@@ -102,6 +102,9 @@ for cin, cout, ks in ((8, 16, 3), (16, 16, 3), (32, 16, 3), (16, 32, 3), (32, 32
     b = torch.randn(cout, generator=g).cuda()
     out.append(ops.conv3d_fwd(x, w, cout, ksize=ks).float().cpu())
     out.append(ops.conv3d_fwd(x, w, cout, ksize=ks, bias=b, cout_store=cout - 12, out_dtype=torch.float32).cpu())
+    base = torch.randn(2, 5, 11, 53, cout, generator=g).bfloat16().cuda()
+    out.append(ops.conv3d_fwd(x, w, cout, ksize=ks, accumulate_into=base.clone()).float().cpu())      # y += conv(x)
+    assert torch.equal(out[-1], (out[-3].float() + base.float().cpu()).bfloat16().float()) or ((out[-1] - (out[-3] + base.float().cpu())).abs().max() < 0.07)
 torch.save(out, sys.argv[1])
 '''
     import os
@@ -114,7 +117,7 @@ torch.save(out, sys.argv[1])
                                cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             assert r.returncode == 0, r.stderr[-2000:]
             res[mode] = torch.load(f, weights_only=True)
-    assert len(res["0"]) == 22
+    assert len(res["0"]) == 33
     for a, b in zip(res["0"], res["2"]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
@@ -182,6 +185,43 @@ def test_tconv_with_skip_writes_the_concatenation_in_place(cin, cout, cs):
         res.append((cat.detach(), xc.grad, wp.grad, sp.grad))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16), (64, 32), (8, 16)])
+def test_fused_res_block_equals_the_chain_of_layer_functions(cin, cout):
+    """UnetResBlockFn (one autograd node; data gradients summed in the kernel epilogue) against conv3x3x3 / instnorm_act_cl / conv1x1x1 chained
+    through autograd: same kernels in the same order, so the forward is bit-identical; the input gradient differs only by where the sum of
+    its two branches is rounded to bf16 (fp32 + bf16 -> bf16 in the epilogue instead of bf16 + bf16 -> bf16)"""
+    from UCF_VIT._hip import conv
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    want_dx = cin % 16 == 0
+    wcin = 1 if cin == 8 else cin
+    x = torch.randn(2, 5, 9, 20, cin, generator=g).bfloat16().cuda()
+    if cin == 8:
+        x[..., 1:] = 0
+    w1 = (torch.randn(cout, wcin, 3, 3, 3, generator=g) * (2.0 / (27 * wcin)) ** 0.5).cuda()
+    w2 = (torch.randn(cout, cout, 3, 3, 3, generator=g) * (2.0 / (27 * cout)) ** 0.5).cuda()
+    w3 = (torch.randn(cout, wcin, 1, 1, 1, generator=g) * wcin ** -0.5).cuda() if wcin != cout else None
+    dy = torch.randn(2, 5, 9, 20, cout, generator=g).bfloat16().cuda()
+    outs = []
+    for fused in (True, False):
+        xc = x.clone().requires_grad_(want_dx)
+        ws = [w.clone().requires_grad_(True) if w is not None else None for w in (w1, w2, w3)]
+        if fused:
+            y = conv.unet_res_block(xc, *ws)
+        else:
+            o = conv.instnorm_act_cl(conv.conv3x3x3(xc, ws[0]), None, 1e-5, 0.01)
+            o = conv.conv3x3x3(o, ws[1])
+            r = conv.instnorm_act_cl(conv.conv1x1x1(xc, ws[2]), None, 1e-5, 1.0) if w3 is not None else xc
+            y = conv.instnorm_act_cl(o, r, 1e-5, 0.01)
+        y.backward(dy)
+        outs.append((y.detach(), xc.grad, [w.grad if w is not None else None for w in ws]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    if want_dx:
+        assert _rel(outs[0][1], outs[1][1]) < 1e-2
 
 
 @pytest.mark.gpu

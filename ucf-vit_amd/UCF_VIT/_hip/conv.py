@@ -91,7 +91,7 @@ def _colsum_narrow(d2):
     return ops.colsum(d2.view(V // f, C * f)).view(f, C).sum(0)
 
 
-def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16):
+def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16, accumulate_into=None):
     """x [B, X, Y, Z, K] bf16 (K one of the kernels' input widths), w2 [N, K] float -> [B, X, Y, Z, cout_store] through the 1x1x1 kernel"""
     n16 = _ceil_to(w2.shape[0], 16)
     if n16 != w2.shape[0]:
@@ -100,7 +100,7 @@ def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16):
             bias = torch.cat((bias, bias.new_zeros(n16 - bias.numel())))
     packed = pack_conv_weight(w2.reshape(n16, w2.shape[1], 1, 1, 1))
     return ops.conv3d_fwd(x, packed, n16, ksize=1, bias=None if bias is None else bias.float().contiguous(), cout_store=cout_store,
-                          out_dtype=out_dtype)
+                          out_dtype=out_dtype, accumulate_into=accumulate_into)
 
 
 def _pointwise_wgrad(x, dy):
@@ -259,6 +259,76 @@ class Conv1x1x1Fn(torch.autograd.Function):
             if has_b and ctx.needs_input_grad[2]:
                 db = ops.colsum(d2)
         return dx, dw, db, None
+
+
+class UnetResBlockFn(torch.autograd.Function):
+    """monai UnetResBlock (kernel 3, stride 1) as ONE autograd node over the channels-last kernels:
+        out = lrelu(norm(conv3(lrelu(norm(conv3(inp, w1))), w2)) + res),   res = norm(conv1(inp, w3)) if w3 is given else inp
+    Against the chain of per-layer functions: the two data gradients that meet in `inp` are summed in the second kernel's epilogue (no
+    torch add over the largest tensors), the normalised 1x1x1 branch is not kept for the backward pass, and the backward of the
+    residual-free normalisations never reads their outputs."""
+
+    @staticmethod
+    def forward(ctx, inp, w1, w2, w3, eps, slope):
+        cout, cin = w1.shape[0], w1.shape[1]
+        cin_x = inp.shape[-1]
+        if cout % 16 or tuple(w1.shape[2:]) != (3, 3, 3) or tuple(w2.shape) != (cout, cout, 3, 3, 3):
+            raise ValueError("UnetResBlock: 3x3x3 weights [Cout, Cin, 3, 3, 3] / [Cout, Cout, 3, 3, 3] with Cout a multiple of 16")
+        if cin_x != cin and not (cin < cin_x == 8):
+            raise ValueError(f"UnetResBlock: input has {cin_x} channels, weight expects {cin}")
+        if w3 is None and cin_x != cout:
+            raise ValueError("UnetResBlock: an identity residual needs Cin == Cout")
+        w1k = w1.detach() if cin_x == cin else torch.cat((w1.detach(), w1.new_zeros((cout, cin_x - cin, 3, 3, 3))), 1)
+        c1 = ops.conv3d_fwd(inp, pack_conv_weight(w1k), cout)
+        y1, m1, r1 = ops.instnorm_cl_fwd(c1, None, eps, slope)
+        c2 = ops.conv3d_fwd(y1, pack_conv_weight(w2.detach()), cout)
+        c3 = m3 = r3 = w3k = None
+        if w3 is not None:
+            w3k = w3.detach().reshape(cout, cin)
+            if cin_x != cin:
+                w3k = torch.cat((w3k, w3k.new_zeros((cout, cin_x - cin))), 1)
+            c3 = _pointwise_fwd(inp, w3k, None, cout)
+            res, m3, r3 = ops.instnorm_cl_fwd(c3, None, eps, 1.0)
+        else:
+            res = inp
+        out, m2, r2 = ops.instnorm_cl_fwd(c2, res, eps, slope)
+        ctx.save_for_backward(inp, w1, w2, w3, c1, y1, c2, c3, out, m1, r1, m2, r2, m3, r3)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inp, w1, w2, w3, c1, y1, c2, c3, out, m1, r1, m2, r2, m3, r3 = ctx.saved_tensors
+        cout, cin = w1.shape[0], w1.shape[1]
+        cin_x = inp.shape[-1]
+        slope = ctx.slope
+        need_dinp = ctx.needs_input_grad[0]
+        dc2, dres = ops.instnorm_cl_bwd(dout, out, c2, m2, r2, slope, want_dres=(w3 is not None or need_dinp), had_res=True)
+        dw2 = unpack_conv_wgrad(ops.conv3d_wgrad(y1, dc2), cout, cout).contiguous() if ctx.needs_input_grad[2] else None
+        dy1 = ops.conv3d_fwd(dc2, pack_conv3_weight_dgrad(w2.detach()), cout)
+        del dc2
+        dc1, _ = ops.instnorm_cl_bwd(dy1, c1, c1, m1, r1, slope, want_dres=False, had_res=False)       # no residual: the output is not read
+        del dy1
+        dw1 = unpack_conv_wgrad(ops.conv3d_wgrad(inp, dc1), cin_x, cout)[:, :cin].contiguous() if ctx.needs_input_grad[1] else None
+        dw3 = dinp = None
+        if w3 is not None:
+            dc3, _ = ops.instnorm_cl_bwd(dres, c3, c3, m3, r3, 1.0, want_dres=False, had_res=False)
+            if ctx.needs_input_grad[3]:
+                dw3 = _pointwise_wgrad(inp, dc3)[:cout, :cin].reshape(cout, cin, 1, 1, 1).contiguous()
+            if need_dinp:
+                w3k = w3.detach().reshape(cout, cin)
+                dinp = _pointwise_fwd(dc3, w3k.t(), None, cin_x)
+        elif need_dinp:
+            dinp = dres
+        if need_dinp:
+            if cin % 16 or cin_x != cin:
+                raise RuntimeError(f"UnetResBlock: no data gradient for a {cin}-channel input")
+            ops.conv3d_fwd(dc1, pack_conv3_weight_dgrad(w1.detach()), cin, accumulate_into=dinp)            # dinp += the 3x3x3 branch
+        return dinp, dw1, dw2, dw3, None, None
+
+
+def unet_res_block(inp, w1, w2, w3=None, eps=1e-5, slope=0.01):
+    return UnetResBlockFn.apply(inp, w1, w2, w3, eps, slope)
 
 
 class InstNormActCLFn(torch.autograd.Function):

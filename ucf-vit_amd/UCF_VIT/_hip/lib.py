@@ -80,7 +80,7 @@ SIGNATURES = {
     "ucfvit_instnorm_cl_workspace": (_I64, [_I64, _I64, _I64]),
     "ucfvit_instnorm_cl_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P]),
     "ucfvit_instnorm_cl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P, _P]),
-    "ucfvit_conv3d_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I64, _I64, _I, _P]),
+    "ucfvit_conv3d_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I64, _I64, _I, _I, _P]),
     "ucfvit_conv3d_wgrad_size": (_I64, [_I64, _I64, _I]),
     "ucfvit_conv3d_wgrad_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64, _I]),
     "ucfvit_conv3d_wgrad": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P]),

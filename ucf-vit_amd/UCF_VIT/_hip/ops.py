@@ -613,7 +613,7 @@ def conv_packed_numel(cin, cout, ksize):
     return (cin // cpc) * (-(-(ksize ** 3) // tps)) * cout * 32
 
 
-def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=torch.bfloat16):
+def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=torch.bfloat16, accumulate_into=None):
     """x [B, X, Y, Z, Cin] bf16, w_packed from conv.pack_conv_weight (cout rows, a multiple of 16) -> y [B, X, Y, Z, cout_store] (ksize 3:
     stride 1, zero padding 1; ksize 1: pointwise).  bias: fp32 [cout] or None."""
     L = _l.load()
@@ -626,9 +626,14 @@ def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype
         if bias.dtype != torch.float32 or bias.numel() != cout:
             raise ValueError("conv3d: bias must be fp32 [Cout]")
     cs = cout if cout_store is None else cout_store
-    y = torch.empty((B, X, Y, Z, cs), dtype=out_dtype, device=x.device)
+    if accumulate_into is not None:                          # y += result: the second data gradient of an input two layers consume
+        y = _chk(accumulate_into, "conv3d.accumulate_into")
+        if tuple(y.shape) != (B, X, Y, Z, cs) or y.dtype != out_dtype:
+            raise ValueError("conv3d: accumulate_into must have the output's shape and dtype")
+    else:
+        y = torch.empty((B, X, Y, Z, cs), dtype=out_dtype, device=x.device)
     _l.check(L.ucfvit_conv3d_fwd(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), B, X, Y, Z, cin, cout, ksize, cs, cs, dt(y),
-                                 _stream()), "ucfvit_conv3d_fwd")
+                                 0 if accumulate_into is None else 1, _stream()), "ucfvit_conv3d_fwd")
     return y
 
 

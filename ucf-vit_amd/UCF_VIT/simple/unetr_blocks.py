@@ -55,12 +55,11 @@ class UnetResBlock(nn.Module):
         return HF.instnorm_act(out, residual, self.norm2.eps, ns)
 
     def forward_cl(self, inp):
-        """inp channels-last bf16 [B, X, Y, Z, Cin] -> [B, X, Y, Z, Cout]"""
-        ns = self.lrelu.negative_slope
-        out = HC.instnorm_act_cl(HC.conv3x3x3(inp, self.conv1.conv.weight), None, self.norm1.eps, ns)
-        out = HC.conv3x3x3(out, self.conv2.conv.weight)
-        residual = HC.instnorm_act_cl(HC.conv1x1x1(inp, self.conv3.conv.weight), None, self.norm3.eps, 1.0) if self.downsample else inp
-        return HC.instnorm_act_cl(out, residual, self.norm2.eps, ns)
+        """inp channels-last bf16 [B, X, Y, Z, Cin] -> [B, X, Y, Z, Cout]: the whole block as one autograd node (_hip/conv.py:UnetResBlockFn)"""
+        if self.norm1.eps != self.norm2.eps or (self.downsample and self.norm3.eps != self.norm1.eps):
+            raise ValueError("UnetResBlock: the fused block takes one eps for its normalisations")
+        return HC.unet_res_block(inp, self.conv1.conv.weight, self.conv2.conv.weight, self.conv3.conv.weight if self.downsample else None,
+                                 self.norm1.eps, self.lrelu.negative_slope)
 
 
 class UnetrBasicBlock(nn.Module):

@@ -47,6 +47,7 @@ struct ConvGeo {
     int tx, ty, tz;      // tile counts along x, y, z
     int tiles;           // B tx ty tz
     int ldy, cout_store; // forward: output row stride (elements) and number of channels written (<= Cout)
+    int accumulate;      // forward: y += result (the second data gradient of an input two layers consume)
 };
 
 // 16-byte load of 8 channels of voxel (b, gx, gy, gz), zero outside the volume (= the convolution's zero padding)
@@ -154,13 +155,18 @@ __global__ __launch_bounds__(CT) void conv_fwd_kernel(const bf16* __restrict__ x
                 for (int e = 0; e < 4; ++e) v[e] = acc[r][nb][e] + (bias ? bias[c + e] : 0.f);
                 if (c + 4 <= g.cout_store && vec_ok) {
                     Vec4<OutT> o;
+                    if (g.accumulate) {
+                        o = *reinterpret_cast<const Vec4<OutT>*>(yp + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += o.get(e);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o.set(e, v[e]);
                     *reinterpret_cast<Vec4<OutT>*>(yp + c) = o;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (c + e < g.cout_store) yp[c + e] = from_f32<OutT>(v[e]);
+                        if (c + e < g.cout_store) yp[c + e] = from_f32<OutT>(v[e] + (g.accumulate ? to_f32<OutT>(yp[c + e]) : 0.f));
                 }
             }
         }
@@ -229,6 +235,21 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
             if (tid + i * CT < NP) *reinterpret_cast<u32x4*>(halo + hoff[i]) = pre[i];
         __syncthreads();
         if (iz + 1 < g.tz) fetch(z0 + 16);              // in flight during the MFMA work below
+        Vec4<OutT> prev[RPW][NB];                       // accumulate: the values to add to, fetched now and used in the epilogue
+        if (g.accumulate && vec_ok) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
+                if (gx < g.X && gy < g.Y && gz < g.Z) {
+                    const OutT* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.ldy;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int c = co0 + nb * 16 + lg * 4;
+                        if (c + 4 <= g.cout_store) prev[r][nb] = *reinterpret_cast<const Vec4<OutT>*>(yp + c);
+                    }
+                }
+            }
+        }
         f32x4 acc[RPW][NB];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -274,13 +295,17 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
                     for (int e = 0; e < 4; ++e) v[e] = acc[r][nb][e] + (bias ? bias[c + e] : 0.f);
                     if (c + 4 <= g.cout_store && vec_ok) {
                         Vec4<OutT> o;
+                        if (g.accumulate) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += prev[r][nb].get(e);
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o.set(e, v[e]);
                         *reinterpret_cast<Vec4<OutT>*>(yp + c) = o;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (c + e < g.cout_store) yp[c + e] = from_f32<OutT>(v[e]);
+                            if (c + e < g.cout_store) yp[c + e] = from_f32<OutT>(v[e] + (g.accumulate ? to_f32<OutT>(yp[c + e]) : 0.f));
                     }
                 }
             }
@@ -609,11 +634,11 @@ int launch_wgrad(const bf16* x, const bf16* dy, float* dw, float* ws, ConvGeo g,
 
 // x [B][X][Y][Z][Cin] bf16, w_packed [Cin/CPC][NTS][Cout][32] bf16, bias fp32 [Cout] or NULL -> y[voxel * ldy + co] for co < cout_store
 extern "C" int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z,
-                                 int64_t Cin, int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, void* stream) {
+                                 int64_t Cin, int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate, void* stream) {
     if (int rc = conv_check("ucfvit_conv3d_fwd", x, w_packed, y, B, X, Y, Z, Cin, Cout, ksize)) return rc;
     UCF_CHECK_ARG(cout_store > 0 && cout_store <= Cout && ldy >= cout_store && ldy < (1ll << 31), "ucfvit_conv3d_fwd: need 0 < cout_store <= Cout, ldy >= cout_store");
     UCF_CHECK_ARG(out_dtype == UCFVIT_BF16 || out_dtype == UCFVIT_F32, "ucfvit_conv3d_fwd: bad out_dtype %d", out_dtype);
-    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, (int)ldy, (int)cout_store};
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, (int)ldy, (int)cout_store, accumulate ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     CONV_SWITCH(Cin, ksize, {
         if (out_dtype == UCFVIT_BF16) return dispatch_fwd<CPC_, KS_, bf16>((const bf16*)x, (const bf16*)w_packed, bias, (bf16*)y, g, s);
@@ -630,7 +655,7 @@ extern "C" int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout, int ksize
 }
 extern "C" int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize) {
     if (!(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0)) || Cout <= 0 || Cout % 16 || !(ksize == 1 || ksize == 3)) return 0;
-    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, 0, 0};
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, 0, 0, 0};
     int n_wg = 0, tpw = 0, gy = 0;
     int64_t n_out = 0;
     CONV_SWITCH(Cin, ksize, {
@@ -646,7 +671,7 @@ extern "C" int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_pack
                                    int64_t Z, int64_t Cin, int64_t Cout, int ksize, void* stream) {
     if (int rc = conv_check("ucfvit_conv3d_wgrad", x, dy, dw_packed, B, X, Y, Z, Cin, Cout, ksize)) return rc;
     UCF_CHECK_ARG(workspace, "ucfvit_conv3d_wgrad: null workspace");
-    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, 0, 0};
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     CONV_SWITCH(Cin, ksize, {
         if (Cout % 32 == 0) return launch_wgrad<CPC_, 2, 2, 4, KS_>((const bf16*)x, (const bf16*)dy, dw_packed, (float*)workspace, g, s);
