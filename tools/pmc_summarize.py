@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 FAMILIES = {
     "gemm": re.compile(r"gemm3_kernel"),
     "attention": re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|s3_fwd|g_bwd)"),
+    "conv": re.compile(r"conv_(fwd|fwd_strip|wgrad)_kernel"),
 }
 
 
