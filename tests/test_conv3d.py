@@ -105,6 +105,13 @@ for cin, cout, ks in ((8, 16, 3), (16, 16, 3), (32, 16, 3), (16, 32, 3), (32, 32
     base = torch.randn(2, 5, 11, 53, cout, generator=g).bfloat16().cuda()
     out.append(ops.conv3d_fwd(x, w, cout, ksize=ks, accumulate_into=base.clone()).float().cpu())      # y += conv(x)
     assert torch.equal(out[-1], (out[-3].float() + base.float().cpu()).bfloat16().float()) or ((out[-1] - (out[-3] + base.float().cpu())).abs().max() < 0.07)
+for cin, cout, Z in ((64, 32, 32), (128, 64, 16), (64, 64, 64), (256, 32, 16), (64, 128, 48)):       # multi-chunk column kernel (Z = 16 / 32 / 64; 48: not eligible)
+    g = torch.Generator().manual_seed(cin + cout + Z)
+    x = torch.randn(2, 5, 11, Z, cin, generator=g).bfloat16().cuda()
+    w = conv.pack_conv_weight(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05).cuda()
+    base = torch.randn(2, 5, 11, Z, cout, generator=g).bfloat16().cuda()
+    out.append(ops.conv3d_fwd(x, w, cout).float().cpu())
+    out.append(ops.conv3d_fwd(x, w, cout, accumulate_into=base.clone()).float().cpu())
 torch.save(out, sys.argv[1])
 '''
     import os
@@ -117,7 +124,7 @@ torch.save(out, sys.argv[1])
                                cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             assert r.returncode == 0, r.stderr[-2000:]
             res[mode] = torch.load(f, weights_only=True)
-    assert len(res["0"]) == 33
+    assert len(res["0"]) == 43
     for a, b in zip(res["0"], res["2"]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 

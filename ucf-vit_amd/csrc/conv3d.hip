@@ -314,6 +314,139 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
     }
 }
 
+// ---- multi-chunk inputs (Cin = 64, 128, 256: the coarser levels), 3x3x3, 32 output channels per workgroup: the same column walk with the
+// channel chunks OUTSIDE the z tiles.  The accumulators of all TZT z tiles of the column stay in registers (Z = 16 TZT <= 64 at these levels),
+// so a chunk's weight slab is staged once per column instead of once per tile, and the halos of the (chunk, z tile) sequence are prefetched
+// through registers like in the single-chunk kernel; for TZT <= 2 the next chunk's weight slab travels through registers as well.
+template <int TZT>
+__global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, bf16* __restrict__ y, ConvGeo g) {
+    typedef CG<32, 3> G;
+    constexpr int NB = 2, TX = 2, TY = 8, HX = 4, HY = 10, HZ = 18;
+    constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
+    constexpr int CB = 32, RPW = 4;
+    constexpr int NP = HX * HY * HZ * G::PPV, NPT = (NP + CT - 1) / CT;
+    constexpr int NWP = G::NTS * CB * 4, NWT = (NWP + CT - 1) / CT;       // 16-byte pieces of a weight slab, per thread
+    constexpr bool WPRE = TZT <= 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wl = smem + HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int iy = t % g.ty;
+    t /= g.ty;
+    const int ix = t % g.tx, b = t / g.tx;
+    const int x0 = ix * TX, y0 = iy * TY;
+    const int co0 = blockIdx.y * CB;
+    int hoff[NPT], hxy[NPT], hzz[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int p = tid + i * CT;
+        const int hv = p / G::PPV, piece = p % G::PPV;
+        const int hz = hv % HZ, hy = (hv / HZ) % HY, hx = hv / (HZ * HY);
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1;
+        const bool ok = p < NP && (unsigned)gx < (unsigned)g.X && (unsigned)gy < (unsigned)g.Y;
+        hoff[i] = hv * G::VS + piece * 16;
+        hxy[i] = ok ? (gx * g.Y + gy) : -1;
+        hzz[i] = ((hz - 1) & 0xffff) | (piece << 16);
+    }
+    const bf16* xb = x + (int64_t)b * g.X * g.Y * g.Z * g.Cin;
+    const int nch = g.Cin / 32, nsteps = nch * TZT;
+    u32x4 pre[NPT];
+    auto fetch = [&](int step) {
+        const int cc = step / TZT, z0 = (step % TZT) * 16;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int gz = z0 + (int)(short)(hzz[i] & 0xffff), piece = hzz[i] >> 16;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (hxy[i] >= 0 && (unsigned)gz < (unsigned)g.Z)
+                v = *reinterpret_cast<const u32x4*>(xb + ((int64_t)hxy[i] * g.Z + gz) * g.Cin + cc * 32 + piece * 8);
+            pre[i] = v;
+        }
+    };
+    u32x4 wpre[WPRE ? NWT : 1];
+    auto wfetch = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int p = tid + i * CT;
+            if (p < NWP) {
+                const int piece = p & 3, row = (p >> 2) % CB, ts = (p >> 2) / CB;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wp + ((int64_t)(cc * G::NTS + ts) * g.Cout + co0 + row) * 32 + piece * 8);
+                if (WPRE)
+                    wpre[i] = v;
+                else
+                    *reinterpret_cast<u32x4*>(wl + p * 16) = v;
+            }
+        }
+    };
+    f32x4 acc[TZT][RPW][NB];
+#pragma unroll
+    for (int z = 0; z < TZT; ++z)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[z][r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    if (WPRE) wfetch(0);
+    for (int cc = 0; cc < nch; ++cc) {
+        // the previous chunk's last tile ended with a barrier: the slab may be overwritten
+        if (WPRE) {
+#pragma unroll
+            for (int i = 0; i < NWT; ++i)
+                if (tid + i * CT < NWP) *reinterpret_cast<u32x4*>(wl + (tid + i * CT) * 16) = wpre[i];
+        } else {
+            wfetch(cc);
+        }
+#pragma unroll
+        for (int z = 0; z < TZT; ++z) {
+            const int step = cc * TZT + z;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                if (tid + i * CT < NP) *reinterpret_cast<u32x4*>(halo + hoff[i]) = pre[i];
+            __syncthreads();
+            if (step + 1 < nsteps) fetch(step + 1);
+            if (WPRE && z == TZT - 1 && cc + 1 < nch) wfetch(cc + 1);
+#pragma unroll
+            for (int ts = 0; ts < G::NTS; ++ts) {
+                frag_t a[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const frag_t*>(wl + ((ts * CB + nb * 16 + li) * 64 + lg * 16));
+                const int dx = ts / 9, dy = (ts / 3) % 3, dz = ts % 3;
+                const int boff = ((dx * HY + dy) * HZ + dz + li) * G::VS + lg * 16;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int row = wave * RPW + r, xl = row / TY, yl = row % TY;
+                    const frag_t bf = *reinterpret_cast<const frag_t*>(halo + boff + (xl * HY + yl) * HZ * G::VS);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[z][r][nb] = mma(a[nb], bf, acc[z][r][nb]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int z = 0; z < TZT; ++z)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z * 16 + li;
+            if (gx < g.X && gy < g.Y && gz < g.Z) {
+                bf16* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.ldy + co0 + lg * 4;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    bf16x4 o;
+                    if (g.accumulate) {
+                        o = *reinterpret_cast<const bf16x4*>(yp + nb * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[z][r][nb][e] + (float)o[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[z][r][nb][e];
+                    }
+                    *reinterpret_cast<bf16x4*>(yp + nb * 16) = o;
+                }
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
 constexpr int TZW = 32;       // z extent of a weight-gradient tile = one 32-deep contraction step per (x, y) row
 
@@ -538,6 +671,25 @@ int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, 
     return UCFVIT_OK;
 }
 
+template <int TZT>
+int launch_fwd_mc(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, hipStream_t s) {
+    g.tx = (g.X + 1) / 2;
+    g.ty = (g.Y + 7) / 8;
+    g.tz = TZT;
+    const int64_t cols = (int64_t)g.B * g.tx * g.ty;
+    UCF_CHECK_ARG(cols < (1ll << 31) && g.Cout / 32 < 65536, "ucfvit_conv3d_fwd: grid too large");
+    g.tiles = (int)cols;
+    constexpr int SMEM = 4 * 10 * 18 * 64 + 27 * 32 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3_fwd_mc_kernel<TZT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3_fwd_mc_kernel<TZT>), dim3((unsigned)cols, g.Cout / 32), dim3(CT), SMEM, s, x, wp, y, g);
+    UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
+    return UCFVIT_OK;
+}
+
 static int strip_mode() {          // UCFVIT_CONV_STRIP: 0 never, 1 (default) when the (x, y) columns fill the chip, 2 whenever the kernel applies (tests)
     static int flag = -1;
     if (flag < 0) {
@@ -550,6 +702,18 @@ static int strip_mode() {          // UCFVIT_CONV_STRIP: 0 never, 1 (default) wh
 template <int CPC, int KS, typename OutT>
 int dispatch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, const ConvGeo& g, hipStream_t s) {
     const int nb16 = g.Cout / 16;
+    // multi-chunk 3x3x3 layers of the coarser levels (bf16 out, no bias, dense output, 32 k output channels, Z = 16 / 32 / 64): chunk-outer column kernel
+    if constexpr (CPC == 32 && KS == 3 && sizeof(OutT) == 2) {
+        if (g.Cin > 32 && !bias && g.Cout % 32 == 0 && g.cout_store == g.Cout && g.ldy == g.Cout && strip_mode() &&
+            (g.Z == 16 || g.Z == 32 || g.Z == 64)) {
+            const int64_t wgs = (int64_t)g.B * ((g.X + 1) / 2) * ((g.Y + 7) / 8) * (g.Cout / 32);
+            if (strip_mode() == 2 || wgs >= 512) {
+                if (g.Z == 16) return launch_fwd_mc<1>(x, wp, (bf16*)y, g, s);
+                if (g.Z == 32) return launch_fwd_mc<2>(x, wp, (bf16*)y, g, s);
+                return launch_fwd_mc<4>(x, wp, (bf16*)y, g, s);
+            }
+        }
+    }
     // single-chunk inputs with at least two z tiles and enough (x, y) columns to fill the chip: the pipelined strip kernel
     if (g.Cin == CPC && g.Z > 16 && strip_mode()) {
         const int64_t cols = (int64_t)g.B * ((g.X + 1) / 2) * ((g.Y + 7) / 8);
