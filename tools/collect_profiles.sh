@@ -15,7 +15,6 @@ for WL in $WLS; do
   run rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o run -- python3 $B --workload $WL --steps 4 --warmup 2 --no-cpu-baseline
 done
 for WL in $WLS; do
-  [ "$WL" = mae_vit_l16_224 ] && continue
   for C in FETCH_SIZE WRITE_SIZE; do
     run rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$WL/$C -o run -- python3 $B --workload $WL --steps 2 --warmup 1 --no-cpu-baseline
   done
