@@ -354,6 +354,19 @@ int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, float* mean,
 int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres, int64_t B,
                            int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* workspace, void* stream);
 
+/* The tail of a residual block whose residual branch is itself normalised (monai UnetResBlock with the 1x1x1 projection):
+ *   ucfvit_instnorm_cl_stats:  mean / rstd of x only (ucfvit_instnorm_cl_fwd = this + the apply pass)
+ *   ucfvit_instnorm_cl_apply2: y = lrelu((x - mean) rstd + (x2 - mean2) rstd2, slope) — the normalised branch is never materialised
+ *   ucfvit_instnorm_cl_bwd2:   dx, dx2 from dy, y (activation mask) and the raw inputs: one pair of passes for both normalisations
+ *                              (workspace: ucfvit_instnorm_cl_bwd2_workspace bytes). */
+int ucfvit_instnorm_cl_stats(const void* x, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, float eps, void* workspace, void* stream);
+int ucfvit_instnorm_cl_apply2(const void* x, const float* mean, const float* rstd, const void* x2, const float* mean2, const float* rstd2, void* y,
+                              int64_t B, int64_t S, int64_t C, float slope, void* stream);
+int64_t ucfvit_instnorm_cl_bwd2_workspace(int64_t B, int64_t S, int64_t C);
+int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const void* x2, const float* mean2,
+                            const float* rstd2, void* dx, void* dx2, int64_t B, int64_t S, int64_t C, int64_t ld_dy, float slope, void* workspace,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * UNETR convolutional decoder, convolutions.  Reference call sites: src/UCF_VIT/simple/arch.py:808-940 — monai's
  * blocks are chains of Conv3d(kernel 3, stride 1, padding 1, no bias) and ConvTranspose3d(kernel 2, stride 2, no bias); these entry

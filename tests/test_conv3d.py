@@ -224,11 +224,27 @@ def test_fused_res_block_equals_the_chain_of_layer_functions(cin, cout):
             y = conv.instnorm_act_cl(o, r, 1e-5, 0.01)
         y.backward(dy)
         outs.append((y.detach(), xc.grad, [w.grad if w is not None else None for w in ws]))
-    assert torch.equal(outs[0][0], outs[1][0])
-    for a, b in zip(outs[0][2], outs[1][2]):
-        assert (a is None and b is None) or torch.equal(a, b)
-    if want_dx:
-        assert _rel(outs[0][1], outs[1][1]) < 1e-2
+    if w3 is None:
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][2], outs[1][2]):
+            assert (a is None and b is None) or torch.equal(a, b)
+    else:
+        # the fused tail lrelu(norm(c2) + norm(c3)) never rounds the normalised 1x1x1 branch (nor its gradient) to bf16, and the normalisation
+        # backward amplifies such roundings: judge both forms against the fp32 restatement of the block on the same operands —
+        # the fused form must be about as close as the chain (slack for the noise of a single draw)
+        from oracle import unetr_decoder_ref as R
+        xr = _ncdhw(x).float()[:, :wcin].requires_grad_(True)
+        wr = [w.detach().bfloat16().float().requires_grad_(True) for w in (w1, w2, w3)]
+        yr = R.res_block(xr, wr[0], wr[1], wr[2])
+        yr.backward(_ncdhw(dy).float())
+        assert _rel(_ncdhw(outs[0][0]), yr) < 1e-2 and _rel(_ncdhw(outs[1][0]), yr) < 1e-2
+        for a, b, ref in zip(outs[0][2], outs[1][2], wr):
+            e_fused, e_chain = _rel(a, ref.grad), _rel(b, ref.grad)
+            assert e_fused < 1.5 * e_chain + 5e-3, (e_fused, e_chain)       # the 1-channel 1x1x1 branch has a pure-cancellation gradient: noisy in both
+        if want_dx:
+            assert _rel(_ncdhw(outs[0][1]), xr.grad) < 1.1 * _rel(_ncdhw(outs[1][1]), xr.grad) + 2e-3
+    if want_dx and w3 is None:
+        assert _rel(outs[0][1], outs[1][1]) < 2e-2
 
 
 @pytest.mark.gpu
@@ -297,6 +313,35 @@ def test_instnorm_channels_last_equals_the_row_layout_kernels_and_torch(C, with_
         y2 = conv.instnorm_act_cl(xc2, _cl(res), 1e-5, slope)
         y2.backward(_cl(dy))
         assert torch.equal(y2, y) and torch.equal(xc2.grad, xc.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [16, 64])
+def test_dual_instnorm_tail_vs_torch(C):
+    """out = lrelu(norm(x) + norm(x2)) (ucfvit_instnorm_cl_stats x 2 + _apply2) and its one-pair-of-passes backward (_bwd2) against torch fp32"""
+    from UCF_VIT._hip import ops
+    g = torch.Generator().manual_seed(C)
+    B, dims = 2, (6, 10, 37)
+    x = (torch.randn(B, C, *dims, generator=g) * 2 + 0.5).bfloat16().cuda()
+    x2 = (torch.randn(B, C, *dims, generator=g) * 0.3 - 1.0).bfloat16().cuda()
+    dy = torch.randn(B, C, *dims, generator=g).bfloat16().cuda()
+    xr, x2r = x.float().requires_grad_(True), x2.float().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5) + F.instance_norm(x2r, eps=1e-5), 0.01)
+    yr.backward(dy.float())
+    xc, x2c = _cl(x), _cl(x2)
+    m, r = ops.instnorm_cl_stats(xc)
+    m2, r2 = ops.instnorm_cl_stats(x2c)
+    assert _rel(m, xr.detach().mean((2, 3, 4))) < 1e-4 and _rel(r2, (x2r.detach().var((2, 3, 4), unbiased=False) + 1e-5).rsqrt()) < 1e-4
+    y = ops.instnorm_cl_apply2(xc, m, r, x2c, m2, r2, 0.01)
+    assert _rel(_ncdhw(y), yr) < 1e-2
+    dx, dx2 = ops.instnorm_cl_bwd2(_cl(dy), y, xc, m, r, x2c, m2, r2, 0.01)
+    # the activation mask comes from the bf16 output: compare where the fp32 reference is not within rounding of zero
+    assert _rel(_ncdhw(dx), xr.grad) < 2e-2 and _rel(_ncdhw(dx2), x2r.grad) < 2e-2
+    # projections of the instance-norm backward: both gradients are orthogonal to the constant and to their own normalised input
+    n2 = (x2r.detach() - x2r.detach().mean((2, 3, 4), keepdim=True)) * (x2r.detach().var((2, 3, 4), unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    d2 = _ncdhw(dx2).float()
+    assert float(d2.mean((2, 3, 4)).abs().max()) < 2e-3 * float(d2.abs().max())
+    assert float((d2 * n2).mean((2, 3, 4)).abs().max()) < 2e-3 * float(d2.abs().max())
 
 
 @pytest.mark.gpu

@@ -288,10 +288,11 @@ class UnetResBlockFn(torch.autograd.Function):
             if cin_x != cin:
                 w3k = torch.cat((w3k, w3k.new_zeros((cout, cin_x - cin))), 1)
             c3 = _pointwise_fwd(inp, w3k, None, cout)
-            res, m3, r3 = ops.instnorm_cl_fwd(c3, None, eps, 1.0)
+            m3, r3 = ops.instnorm_cl_stats(c3, eps)
+            m2, r2 = ops.instnorm_cl_stats(c2, eps)
+            out = ops.instnorm_cl_apply2(c2, m2, r2, c3, m3, r3, slope)        # lrelu(norm(c2) + norm(c3)): the normalised branch is never written
         else:
-            res = inp
-        out, m2, r2 = ops.instnorm_cl_fwd(c2, res, eps, slope)
+            out, m2, r2 = ops.instnorm_cl_fwd(c2, inp, eps, slope)
         ctx.save_for_backward(inp, w1, w2, w3, c1, y1, c2, c3, out, m1, r1, m2, r2, m3, r3)
         ctx.slope = slope
         return out
@@ -303,7 +304,11 @@ class UnetResBlockFn(torch.autograd.Function):
         cin_x = inp.shape[-1]
         slope = ctx.slope
         need_dinp = ctx.needs_input_grad[0]
-        dc2, dres = ops.instnorm_cl_bwd(dout, out, c2, m2, r2, slope, want_dres=(w3 is not None or need_dinp), had_res=True)
+        if w3 is not None:
+            dc2, dc3 = ops.instnorm_cl_bwd2(dout, out, c2, m2, r2, c3, m3, r3, slope)                   # both normalisations in one pair of passes
+            dres = None
+        else:
+            dc2, dres = ops.instnorm_cl_bwd(dout, out, c2, m2, r2, slope, want_dres=need_dinp, had_res=True)
         dw2 = unpack_conv_wgrad(ops.conv3d_wgrad(y1, dc2), cout, cout).contiguous() if ctx.needs_input_grad[2] else None
         dy1 = ops.conv3d_fwd(dc2, pack_conv3_weight_dgrad(w2.detach()), cout)
         del dc2
@@ -312,7 +317,6 @@ class UnetResBlockFn(torch.autograd.Function):
         dw1 = unpack_conv_wgrad(ops.conv3d_wgrad(inp, dc1), cin_x, cout)[:, :cin].contiguous() if ctx.needs_input_grad[1] else None
         dw3 = dinp = None
         if w3 is not None:
-            dc3, _ = ops.instnorm_cl_bwd(dres, c3, c3, m3, r3, 1.0, want_dres=False, had_res=False)
             if ctx.needs_input_grad[3]:
                 dw3 = _pointwise_wgrad(inp, dc3)[:cout, :cin].reshape(cout, cin, 1, 1, 1).contiguous()
             if need_dinp:

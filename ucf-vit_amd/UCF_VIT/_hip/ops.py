@@ -743,6 +743,51 @@ def instnorm_cl_fwd(x, res=None, eps=1e-5, slope=0.01):
     return y, mean, rstd
 
 
+def instnorm_cl_stats(x, eps=1e-5):
+    """-> (mean [B, C], rstd [B, C]) of a channels-last bf16 map"""
+    L = _l.load()
+    _chk_cl(x, "instnorm_cl_stats.x")
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
+    _l.check(L.ucfvit_instnorm_cl_stats(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, S, C, eps, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_stats")
+    return mean, rstd
+
+
+def instnorm_cl_apply2(x, mean, rstd, x2, mean2, rstd2, slope):
+    """y = lrelu(norm(x) + norm(x2)) with both statistics given"""
+    L = _l.load()
+    _chk_cl(x, "instnorm_cl_apply2.x"), _chk_cl(x2, "instnorm_cl_apply2.x2")
+    if x2.shape != x.shape:
+        raise ValueError("instnorm_cl_apply2: the two branches must have one shape")
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    _l.check(L.ucfvit_instnorm_cl_apply2(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), y.data_ptr(),
+                                         B, S, C, slope, _stream()), "ucfvit_instnorm_cl_apply2")
+    return y
+
+
+def instnorm_cl_bwd2(dy, y, x, mean, rstd, x2, mean2, rstd2, slope):
+    """backward of instnorm_cl_apply2 -> (dx, dx2); dy may be a channel slice of a wider channels-last gradient"""
+    L = _l.load()
+    _chk_cl(x, "instnorm_cl_bwd2.x")
+    ld = cl_row_stride(dy)
+    if ld is None or dy.shape != x.shape:
+        dy = _chk_cl(dy.contiguous(), "instnorm_cl_bwd2.dy")
+        ld = dy.shape[-1]
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x)
+    ws = workspace(L.ucfvit_instnorm_cl_bwd2_workspace(B, S, C), x.device)
+    _l.check(L.ucfvit_instnorm_cl_bwd2(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x2.data_ptr(), mean2.data_ptr(),
+                                       rstd2.data_ptr(), dx.data_ptr(), dx2.data_ptr(), B, S, C, ld, slope, ws.data_ptr(), _stream()),
+             "ucfvit_instnorm_cl_bwd2")
+    return dx, dx2
+
+
 def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres, had_res=None):
     """dy may be a channel slice of a wider channels-last gradient (the skip half of a concatenation's gradient): read in place"""
     L = _l.load()

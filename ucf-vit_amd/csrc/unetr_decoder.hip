@@ -472,6 +472,139 @@ __global__ __launch_bounds__(NT) void incl_bwd_apply(const bf16* __restrict__ dy
         if (WRES) drb[i] = orr;
     }
 }
+// ---- residual block tail with a NORMALISED residual branch: out = lrelu(norm(x) + norm(x2)) (monai UnetResBlock with the 1x1x1 projection:
+// x = conv2 output, x2 = conv3 output).  Against norm(x2) as its own apply pass + a residual read: the normalised branch is never written or
+// re-read (2 tensor passes less forward), and the backward needs ONE pair of passes for both normalisations (3 passes less): the activation
+// mask and dn are shared, only the projections differ:  dx = r (dn - mean(dn) - n mean(dn n)),  dx2 = r2 (dn - mean(dn) - n2 mean(dn n2)).
+__global__ __launch_bounds__(NT) void incl_apply2(const bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const bf16* __restrict__ x2, const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                  bf16* __restrict__ y, int64_t S, int C, float slope) {
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3, cg = threadIdx.x % cv;
+    float m[8], r[8], m2[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m[e] = mean[b * C + cg * 8 + e];
+        r[e] = rstd[b * C + cg * 8 + e];
+        m2[e] = mean2[b * C + cg * 8 + e];
+        r2[e] = rstd2[b * C + cg * 8 + e];
+    }
+    const int64_t nvec = S * cv;
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    const bf16x8* x2b = reinterpret_cast<const bf16x8*>(x2 + b * S * C);
+    bf16x8* yb = reinterpret_cast<bf16x8*>(y + b * S * C);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
+        const bf16x8 xv = xb[i], zv = x2b[i];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = ((float)xv[e] - m[e]) * r[e] + ((float)zv[e] - m2[e]) * r2[e];       // the branch value is never rounded to bf16
+            o[e] = (bf16)(v >= 0.f ? v : v * slope);
+        }
+        yb[i] = o;
+    }
+}
+__global__ __launch_bounds__(NT) void incl_bwd2_partial(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd, const bf16* __restrict__ x2,
+                                                        const float* __restrict__ mean2, const float* __restrict__ rstd2, float* __restrict__ part,
+                                                        int64_t S, int C, int chunks, float slope, int64_t ldg8) {
+    __shared__ float red[NT][25];
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3, cg = threadIdx.x % cv, cvs = __builtin_ctz(cv);
+    float m[8], r[8], m2[8], r2[8], s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m[e] = mean[b * C + cg * 8 + e];
+        r[e] = rstd[b * C + cg * 8 + e];
+        m2[e] = mean2[b * C + cg * 8 + e];
+        r2[e] = rstd2[b * C + cg * 8 + e];
+        s1[e] = s2[e] = s3[e] = 0.f;
+    }
+    const int64_t nvec = S * cv, vlo = (int64_t)blockIdx.x * CLV, vhi = min(nvec, vlo + CLV);
+    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy) + b * S * ldg8;
+    const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    const bf16x8* x2b = reinterpret_cast<const bf16x8*>(x2 + b * S * C);
+    for (int64_t i = vlo + threadIdx.x; i < vhi; i += NT) {
+        const bf16x8 gv = gb[(i >> cvs) * ldg8 + cg], yv = yb[i], xv = xb[i], zv = x2b[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dn = (float)gv[e] * ((float)yv[e] > 0.f ? 1.f : slope);
+            s1[e] += dn;
+            s2[e] += dn * ((float)xv[e] - m[e]) * r[e];
+            s3[e] += dn * ((float)zv[e] - m2[e]) * r2[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[threadIdx.x][e] = s1[e];
+        red[threadIdx.x][8 + e] = s2[e];
+        red[threadIdx.x][16 + e] = s3[e];
+    }
+    __syncthreads();
+    float* out = part + (b * chunks + blockIdx.x) * 3 * C;
+    for (int o = threadIdx.x; o < 3 * C; o += NT) {
+        const int k = o / C, c = o % C, cgo = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int t = cgo; t < NT; t += cv) s += red[t][k * 8 + e];
+        out[o] = s;                                                 // [3][C]
+    }
+}
+__global__ __launch_bounds__(64) void incl_bwd2_final(const float* __restrict__ part, float* __restrict__ mm, int64_t S, int C, int chunks, int BC) {
+    const int64_t b = blockIdx.x / C;
+    const int c = blockIdx.x % C;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int ch = threadIdx.x; ch < chunks; ch += 64)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += part[(b * chunks + ch) * 3 * C + k * C + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mm[k * BC + blockIdx.x] = (float)(s[k] / (double)S);
+}
+__global__ __launch_bounds__(NT) void incl_bwd2_apply(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd, const bf16* __restrict__ x2,
+                                                      const float* __restrict__ mean2, const float* __restrict__ rstd2, const float* __restrict__ mm,
+                                                      bf16* __restrict__ dx, bf16* __restrict__ dx2, int64_t S, int C, float slope, int64_t ldg8,
+                                                      int BC) {
+    const int64_t b = blockIdx.y;
+    const int cv = C >> 3, cg = threadIdx.x % cv, cvs = __builtin_ctz(cv);
+    float m[8], r[8], m2[8], r2[8], a1[8], a2[8], a3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t k = b * C + cg * 8 + e;
+        m[e] = mean[k];
+        r[e] = rstd[k];
+        m2[e] = mean2[k];
+        r2[e] = rstd2[k];
+        a1[e] = mm[k];
+        a2[e] = mm[BC + k];
+        a3[e] = mm[2 * BC + k];
+    }
+    const int64_t nvec = S * cv;
+    const bf16x8* gb = reinterpret_cast<const bf16x8*>(dy) + b * S * ldg8;
+    const bf16x8* yb = reinterpret_cast<const bf16x8*>(y + b * S * C);
+    const bf16x8* xb = reinterpret_cast<const bf16x8*>(x + b * S * C);
+    const bf16x8* x2b = reinterpret_cast<const bf16x8*>(x2 + b * S * C);
+    bf16x8* dxb = reinterpret_cast<bf16x8*>(dx + b * S * C);
+    bf16x8* dx2b = reinterpret_cast<bf16x8*>(dx2 + b * S * C);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
+        const bf16x8 gv = gb[(i >> cvs) * ldg8 + cg], yv = yb[i], xv = xb[i], zv = x2b[i];
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dn = (float)gv[e] * ((float)yv[e] > 0.f ? 1.f : slope);
+            const float n = ((float)xv[e] - m[e]) * r[e], n2 = ((float)zv[e] - m2[e]) * r2[e];
+            o1[e] = (bf16)(r[e] * (dn - a1[e] - n * a2[e]));
+            o2[e] = (bf16)(r2[e] * (dn - a1[e] - n2 * a3[e]));
+        }
+        dxb[i] = o1;
+        dx2b[i] = o2;
+    }
+}
 int cl_chunks_of(int64_t S, int64_t C) { return (int)((S * (C / 8) + CLV - 1) / CLV); }
 unsigned cl_apply_grid(int64_t S, int64_t C, int64_t B) {
     int64_t g = (S * (C / 8) + NT - 1) / NT;
@@ -648,5 +781,54 @@ extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void*
         INCL_BWD_APPLY(false, false);
 #undef INCL_BWD_APPLY
     UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd");
+    return UCFVIT_OK;
+}
+
+// statistics only (mean, rstd [B][C]); ucfvit_instnorm_cl_fwd = this + the apply pass
+extern "C" int ucfvit_instnorm_cl_stats(const void* x, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, float eps, void* workspace,
+                                        void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_stats", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(mean && rstd && workspace, "ucfvit_instnorm_cl_stats: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = cl_chunks_of(S, C);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(incl_stats_partial, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)x, part, S, (int)C, ch);
+    hipLaunchKernelGGL(incl_stats_final, dim3((unsigned)(B * C)), dim3(64), 0, s, (const bf16*)x, part, mean, rstd, S, (int)C, ch, eps);
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_stats");
+    return UCFVIT_OK;
+}
+// y = lrelu((x - mean) rstd + (x2 - mean2) rstd2, slope): both statistics given (ucfvit_instnorm_cl_stats)
+extern "C" int ucfvit_instnorm_cl_apply2(const void* x, const float* mean, const float* rstd, const void* x2, const float* mean2, const float* rstd2,
+                                         void* y, int64_t B, int64_t S, int64_t C, float slope, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_apply2", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(mean && rstd && x2 && mean2 && rstd2 && y && ucf_is_aligned16(x2) && ucf_is_aligned16(y), "ucfvit_instnorm_cl_apply2: bad pointer");
+    const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+    hipLaunchKernelGGL(incl_apply2, g, dim3(NT), 0, (hipStream_t)stream, (const bf16*)x, mean, rstd, (const bf16*)x2, mean2, rstd2, (bf16*)y, S, (int)C,
+                       slope);
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_apply2");
+    return UCFVIT_OK;
+}
+extern "C" int64_t ucfvit_instnorm_cl_bwd2_workspace(int64_t B, int64_t S, int64_t C) {
+    return (B * cl_chunks_of(S, C) * 3 * C + 3 * B * C) * (int64_t)sizeof(float);
+}
+// backward of ucfvit_instnorm_cl_apply2: dx, dx2 from dy, the saved output y (activation mask) and the two raw inputs with their statistics
+extern "C" int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const void* x2,
+                                       const float* mean2, const float* rstd2, void* dx, void* dx2, int64_t B, int64_t S, int64_t C, int64_t ld_dy,
+                                       float slope, void* workspace, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_bwd2", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(ld_dy >= C && ld_dy % 8 == 0 && ucf_is_aligned16(dy), "ucfvit_instnorm_cl_bwd2: ld_dy must be a multiple of 8 and >= C");
+    UCF_CHECK_ARG(dy && y && mean && rstd && x2 && mean2 && rstd2 && dx && dx2 && workspace, "ucfvit_instnorm_cl_bwd2: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = cl_chunks_of(S, C);
+    const int64_t ldg8 = ld_dy / 8;
+    float* part = (float*)workspace;
+    float* mm = part + B * ch * 3 * C;
+    hipLaunchKernelGGL(incl_bwd2_partial, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
+                       (const bf16*)x2, mean2, rstd2, part, S, (int)C, ch, slope, ldg8);
+    hipLaunchKernelGGL(incl_bwd2_final, dim3((unsigned)(B * C)), dim3(64), 0, s, part, mm, S, (int)C, ch, (int)(B * C));
+    const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+    hipLaunchKernelGGL(incl_bwd2_apply, g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, (const bf16*)x2, mean2, rstd2, mm,
+                       (bf16*)dx, (bf16*)dx2, S, (int)C, slope, ldg8, (int)(B * C));
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd2");
     return UCFVIT_OK;
 }
