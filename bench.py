@@ -209,7 +209,7 @@ class KernelProfiler:
 
         # 3x3x3 and 1x1x1 convolutions (csrc/conv3d.hip): 2 x taps x voxels x Cin x Cout per forward / data-gradient / weight-gradient
         # launch, with the operand widths as launched (the zero channels of the 8-channel input operand are 1 % of the total)
-        def conv_flops(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=None, accumulate_into=None):
+        def conv_flops(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=None, accumulate_into=None, stats_eps=None):
             return 2.0 * ksize ** 3 * x.numel() * (cout_store or cout)
         ops.conv3d_fwd = self._timed("conv", ops.conv3d_fwd, conv_flops)
         ops.conv3d_wgrad = self._timed("conv", ops.conv3d_wgrad, lambda x, dy, ksize=3: 2.0 * ksize ** 3 * x.numel() * dy.shape[-1])

@@ -360,6 +360,8 @@ int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const f
  *   ucfvit_instnorm_cl_bwd2:   dx, dx2 from dy, y (activation mask) and the raw inputs: one pair of passes for both normalisations
  *                              (workspace: ucfvit_instnorm_cl_bwd2_workspace bytes). */
 int ucfvit_instnorm_cl_stats(const void* x, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, float eps, void* workspace, void* stream);
+int ucfvit_instnorm_cl_apply(const void* x, const void* res, void* y, const float* mean, const float* rstd, int64_t B, int64_t S, int64_t C,
+                             float slope, void* stream); /* the apply pass alone, statistics given */
 int ucfvit_instnorm_cl_apply2(const void* x, const float* mean, const float* rstd, const void* x2, const float* mean2, const float* rstd2, void* y,
                               int64_t B, int64_t S, int64_t C, float slope, void* stream);
 int64_t ucfvit_instnorm_cl_bwd2_workspace(int64_t B, int64_t S, int64_t C);
@@ -379,6 +381,9 @@ int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void* x, const 
  *   fp32 (out_dtype).  Cin in {8, 16, 32 k}, Cout = 16 k = the rows of w_packed; cout_store <= Cout channels are written with row stride
  *   ldy (a 4-class head writes [V][4] from a 16-row weight block); bias fp32 [Cout] or NULL; accumulate: y += result (the second of two
  *   data gradients that flow into the same input, e.g. a residual block's 3x3x3 and 1x1x1 branches).
+ *   stats_partial (may be NULL): the instance-norm statistics of the OUTPUT as a by-product — per-channel sum and sum of squares of the
+ *   rounded outputs, [B][rows][2][Cout] fp32 with rows = ucfvit_conv3d_fwd_stats_rows(...) (0: the kernel serving this shape has no such
+ *   epilogue); ucfvit_instnorm_cl_stats_fold turns them into mean / rstd, which saves the statistics pass over the output.
  *   w_packed (bf16) holds the weights per 32-wide contraction step: with CPC = min(Cin, 32), TPS = 32 / CPC taps per step and
  *   NTS = ceil(ksize^3 / TPS) steps per channel chunk, w_packed[cc][ts][co][kk] = w[co][cc CPC + kk % CPC][tap] for tap = ts TPS + kk / CPC
  *   (zero when tap >= ksize^3); tap = (dx 3 + dy) 3 + dz.  The data gradient is the same call on dy with the flipped, transposed weights.
@@ -395,7 +400,10 @@ int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void* x, const 
  *   an operand of the kernels above.
  * ------------------------------------------------------------------------------------------------------ */
 int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
-                      int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate, void* stream);
+                      int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate, float* stats_partial, void* stream);
+int64_t ucfvit_conv3d_fwd_stats_rows(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize, int has_bias);
+int ucfvit_instnorm_cl_stats_fold(const float* partial, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, int64_t rows, float eps,
+                                  void* workspace /* B * 256 * 2 C floats, or NULL */, void* stream);
 int64_t ucfvit_conv3d_wgrad_size(int64_t Cin, int64_t Cout, int ksize);
 int64_t ucfvit_conv3d_wgrad_workspace(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize);
 int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* workspace, int64_t B, int64_t X, int64_t Y, int64_t Z,

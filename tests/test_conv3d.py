@@ -112,6 +112,17 @@ for cin, cout, Z in ((64, 32, 32), (128, 64, 16), (64, 64, 64), (256, 32, 16), (
     base = torch.randn(2, 5, 11, Z, cout, generator=g).bfloat16().cuda()
     out.append(ops.conv3d_fwd(x, w, cout).float().cpu())
     out.append(ops.conv3d_fwd(x, w, cout, accumulate_into=base.clone()).float().cpu())
+# instance-norm statistics of the output from the epilogue (column kernels) / from a pass over the output (tile kernel): same numbers
+for cin, cout, ks, Z, XY in ((16, 16, 3, 53, (5, 11)), (32, 32, 3, 40, (5, 11)), (8, 16, 1, 53, (5, 11)), (64, 32, 3, 32, (5, 11)), (32, 64, 1, 21, (5, 11)),
+                             (16, 16, 3, 40, (64, 96))):           # the last: 768 partial rows per batch element -> two-stage fold
+    g = torch.Generator().manual_seed(cin + cout + ks + Z)
+    x = torch.randn(2, XY[0], XY[1], Z, cin, generator=g).bfloat16().cuda()
+    w = conv.pack_conv_weight(torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.1).cuda()
+    yv, mean, rstd = ops.conv3d_fwd(x, w, cout, ksize=ks, stats_eps=1e-5)
+    ref = yv.float().reshape(2, -1, cout)
+    assert ((mean - ref.mean(1)).abs().max() / ref.std(1).max()).item() < 1e-4
+    assert ((rstd * (ref.var(1, unbiased=False) + 1e-5).sqrt() - 1).abs().max()).item() < 1e-4
+    out += [yv.float().cpu(), mean.cpu(), rstd.cpu()]
 torch.save(out, sys.argv[1])
 '''
     import os
@@ -124,9 +135,13 @@ torch.save(out, sys.argv[1])
                                cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             assert r.returncode == 0, r.stderr[-2000:]
             res[mode] = torch.load(f, weights_only=True)
-    assert len(res["0"]) == 43
-    for a, b in zip(res["0"], res["2"]):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert len(res["0"]) == 61
+    for i, (a, b) in enumerate(zip(res["0"], res["2"])):
+        assert torch.isfinite(a).all()
+        if i < 43 or (i - 43) % 3 == 0:
+            assert torch.equal(a, b)                                      # outputs: bit-identical
+        else:
+            assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5       # statistics: two summation orders of the same numbers
 
 
 @pytest.mark.gpu

@@ -91,7 +91,7 @@ def _colsum_narrow(d2):
     return ops.colsum(d2.view(V // f, C * f)).view(f, C).sum(0)
 
 
-def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16, accumulate_into=None):
+def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16, accumulate_into=None, stats_eps=None):
     """x [B, X, Y, Z, K] bf16 (K one of the kernels' input widths), w2 [N, K] float -> [B, X, Y, Z, cout_store] through the 1x1x1 kernel"""
     n16 = _ceil_to(w2.shape[0], 16)
     if n16 != w2.shape[0]:
@@ -100,7 +100,7 @@ def _pointwise_fwd(x, w2, bias, cout_store, out_dtype=torch.bfloat16, accumulate
             bias = torch.cat((bias, bias.new_zeros(n16 - bias.numel())))
     packed = pack_conv_weight(w2.reshape(n16, w2.shape[1], 1, 1, 1))
     return ops.conv3d_fwd(x, packed, n16, ksize=1, bias=None if bias is None else bias.float().contiguous(), cout_store=cout_store,
-                          out_dtype=out_dtype, accumulate_into=accumulate_into)
+                          out_dtype=out_dtype, accumulate_into=accumulate_into, stats_eps=stats_eps)
 
 
 def _pointwise_wgrad(x, dy):
@@ -279,20 +279,21 @@ class UnetResBlockFn(torch.autograd.Function):
         if w3 is None and cin_x != cout:
             raise ValueError("UnetResBlock: an identity residual needs Cin == Cout")
         w1k = w1.detach() if cin_x == cin else torch.cat((w1.detach(), w1.new_zeros((cout, cin_x - cin, 3, 3, 3))), 1)
-        c1 = ops.conv3d_fwd(inp, pack_conv_weight(w1k), cout)
-        y1, m1, r1 = ops.instnorm_cl_fwd(c1, None, eps, slope)
-        c2 = ops.conv3d_fwd(y1, pack_conv_weight(w2.detach()), cout)
+        # every convolution hands over the instance-norm statistics of its output (epilogue by-product where the kernel has one)
+        c1, m1, r1 = ops.conv3d_fwd(inp, pack_conv_weight(w1k), cout, stats_eps=eps)
+        y1 = ops.instnorm_cl_apply(c1, m1, r1, None, slope)
+        c2, m2, r2 = ops.conv3d_fwd(y1, pack_conv_weight(w2.detach()), cout, stats_eps=eps)
         c3 = m3 = r3 = w3k = None
         if w3 is not None:
             w3k = w3.detach().reshape(cout, cin)
             if cin_x != cin:
                 w3k = torch.cat((w3k, w3k.new_zeros((cout, cin_x - cin))), 1)
-            c3 = _pointwise_fwd(inp, w3k, None, cout)
-            m3, r3 = ops.instnorm_cl_stats(c3, eps)
-            m2, r2 = ops.instnorm_cl_stats(c2, eps)
+            if cout % 16:
+                raise ValueError("UnetResBlock: Cout must be a multiple of 16")
+            c3, m3, r3 = _pointwise_fwd(inp, w3k, None, cout, stats_eps=eps)
             out = ops.instnorm_cl_apply2(c2, m2, r2, c3, m3, r3, slope)        # lrelu(norm(c2) + norm(c3)): the normalised branch is never written
         else:
-            out, m2, r2 = ops.instnorm_cl_fwd(c2, inp, eps, slope)
+            out = ops.instnorm_cl_apply(c2, m2, r2, inp, slope)
         ctx.save_for_backward(inp, w1, w2, w3, c1, y1, c2, c3, out, m1, r1, m2, r2, m3, r3)
         ctx.slope = slope
         return out

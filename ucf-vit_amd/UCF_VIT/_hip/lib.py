@@ -81,10 +81,13 @@ SIGNATURES = {
     "ucfvit_instnorm_cl_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P]),
     "ucfvit_instnorm_cl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P, _P]),
     "ucfvit_instnorm_cl_stats": (c_int, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
+    "ucfvit_instnorm_cl_apply": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P]),
     "ucfvit_instnorm_cl_apply2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _P]),
     "ucfvit_instnorm_cl_bwd2_workspace": (_I64, [_I64, _I64, _I64]),
     "ucfvit_instnorm_cl_bwd2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, _P]),
-    "ucfvit_conv3d_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I64, _I64, _I, _I, _P]),
+    "ucfvit_conv3d_fwd": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I64, _I64, _I, _I, _P, _P]),
+    "ucfvit_conv3d_fwd_stats_rows": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64, _I, _I]),
+    "ucfvit_instnorm_cl_stats_fold": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, _P]),
     "ucfvit_conv3d_wgrad_size": (_I64, [_I64, _I64, _I]),
     "ucfvit_conv3d_wgrad_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64, _I]),
     "ucfvit_conv3d_wgrad": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P]),

@@ -613,7 +613,7 @@ def conv_packed_numel(cin, cout, ksize):
     return (cin // cpc) * (-(-(ksize ** 3) // tps)) * cout * 32
 
 
-def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=torch.bfloat16, accumulate_into=None):
+def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype=torch.bfloat16, accumulate_into=None, stats_eps=None):
     """x [B, X, Y, Z, Cin] bf16, w_packed from conv.pack_conv_weight (cout rows, a multiple of 16) -> y [B, X, Y, Z, cout_store] (ksize 3:
     stride 1, zero padding 1; ksize 1: pointwise).  bias: fp32 [cout] or None."""
     L = _l.load()
@@ -632,9 +632,26 @@ def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype
             raise ValueError("conv3d: accumulate_into must have the output's shape and dtype")
     else:
         y = torch.empty((B, X, Y, Z, cs), dtype=out_dtype, device=x.device)
+    part, rows = None, 0
+    if stats_eps is not None:
+        # instance-norm statistics of the output as a by-product of the epilogue where the serving kernel has one, else one pass over y
+        if accumulate_into is not None or cs != cout or out_dtype != torch.bfloat16:
+            raise ValueError("conv3d: statistics need a dense bf16 output without accumulation")
+        rows = L.ucfvit_conv3d_fwd_stats_rows(B, X, Y, Z, cin, cout, ksize, 0 if bias is None else 1)
+        if rows:
+            buf = workspace((B * rows * 2 * cout + B * 256 * 2 * cout) * 4, x.device)       # partials, then the first fold stage's scratch
+            part, fold_ws = buf, buf[B * rows * 2 * cout:]
     _l.check(L.ucfvit_conv3d_fwd(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), B, X, Y, Z, cin, cout, ksize, cs, cs, dt(y),
-                                 0 if accumulate_into is None else 1, _stream()), "ucfvit_conv3d_fwd")
-    return y
+                                 0 if accumulate_into is None else 1, _p(part), _stream()), "ucfvit_conv3d_fwd")
+    if stats_eps is None:
+        return y
+    if not rows:
+        return (y,) + instnorm_cl_stats(y, stats_eps)
+    mean = torch.empty((B, cout), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, cout), dtype=torch.float32, device=x.device)
+    _l.check(L.ucfvit_instnorm_cl_stats_fold(part.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, X * Y * Z, cout, rows, stats_eps, fold_ws.data_ptr(),
+                                             _stream()), "ucfvit_instnorm_cl_stats_fold")
+    return y, mean, rstd
 
 
 def conv3d_wgrad(x, dy, ksize=3):
@@ -754,6 +771,22 @@ def instnorm_cl_stats(x, eps=1e-5):
     ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
     _l.check(L.ucfvit_instnorm_cl_stats(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, S, C, eps, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_stats")
     return mean, rstd
+
+
+def instnorm_cl_apply(x, mean, rstd, res=None, slope=0.01):
+    """y = lrelu((x - mean) rstd [+ res], slope) with the statistics given"""
+    L = _l.load()
+    _chk_cl(x, "instnorm_cl_apply.x")
+    if res is not None:
+        _chk_cl(res, "instnorm_cl_apply.res")
+        if res.shape != x.shape:
+            raise ValueError("instnorm_cl_apply: res must have the shape of x")
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    _l.check(L.ucfvit_instnorm_cl_apply(x.data_ptr(), _p(res), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, S, C, slope, _stream()),
+             "ucfvit_instnorm_cl_apply")
+    return y
 
 
 def instnorm_cl_apply2(x, mean, rstd, x2, mean2, rstd2, slope):

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(CT) void conv_fwd_kernel(const bf16* __restrict__ x
 // ~60..100 MFMAs per wave per tile) is hidden behind the MFMA work.
 template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
 __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias,
-                                                            OutT* __restrict__ y, ConvGeo g) {
+                                                            OutT* __restrict__ y, ConvGeo g, float* __restrict__ stats) {
     typedef CG<CPC, KS> G;
     constexpr int PAD = G::PAD, HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = 16 + 2 * PAD;
     constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
@@ -228,6 +228,13 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
     };
     fetch(0);
     const bool vec_ok = (g.ldy & 3) == 0;
+    // stats (optional): per-channel sum and sum of squares of the ROUNDED outputs of this column, per wave — the instance-norm statistics of the
+    // layer's output without a pass over it ([column * 4 + wave][2][Cout] partials, folded by ucfvit_instnorm_cl_stats_fold)
+    float st1[NB][4], st2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[nb][e] = st2[nb][e] = 0.f;
     for (int iz = 0; iz < g.tz; ++iz) {
         const int z0 = iz * 16;
 #pragma unroll
@@ -302,6 +309,14 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o.set(e, v[e]);
                         *reinterpret_cast<Vec4<OutT>*>(yp + c) = o;
+                        if (stats) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float q = o.get(e);
+                                st1[nb][e] += q;
+                                st2[nb][e] = fmaf(q, q, st2[nb][e]);
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -312,6 +327,25 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
         }
         __syncthreads();                                // every wave is done with this halo before the next one is written
     }
+    if (stats) {
+        float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 * g.Cout;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = st1[nb][e], q = st2[nb][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {                  // over the 16 voxel lanes of a channel group
+                    a += __shfl_xor(a, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if (li == 0) {
+                    const int c = co0 + nb * 16 + lg * 4 + e;
+                    sp[c] = a;
+                    sp[g.Cout + c] = q;
+                }
+            }
+    }
 }
 
 // ---- multi-chunk inputs (Cin = 64, 128, 256: the coarser levels), 3x3x3, 32 output channels per workgroup: the same column walk with the
@@ -319,7 +353,8 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
 // so a chunk's weight slab is staged once per column instead of once per tile, and the halos of the (chunk, z tile) sequence are prefetched
 // through registers like in the single-chunk kernel; for TZT <= 2 the next chunk's weight slab travels through registers as well.
 template <int TZT>
-__global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, bf16* __restrict__ y, ConvGeo g) {
+__global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, bf16* __restrict__ y, ConvGeo g,
+                                                          float* __restrict__ stats) {
     typedef CG<32, 3> G;
     constexpr int NB = 2, TX = 2, TY = 8, HX = 4, HY = 10, HZ = 18;
     constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
@@ -423,6 +458,11 @@ __global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict
             __syncthreads();
         }
     }
+    float st1[NB][4], st2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[nb][e] = st2[nb][e] = 0.f;
 #pragma unroll
     for (int z = 0; z < TZT; ++z)
 #pragma unroll
@@ -442,9 +482,36 @@ __global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict
                         for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[z][r][nb][e];
                     }
                     *reinterpret_cast<bf16x4*>(yp + nb * 16) = o;
+                    if (stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = (float)o[e];
+                            st1[nb][e] += q;
+                            st2[nb][e] = fmaf(q, q, st2[nb][e]);
+                        }
+                    }
                 }
             }
         }
+    if (stats) {                                                    // see conv_fwd_strip_kernel
+        float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 * g.Cout;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = st1[nb][e], q = st2[nb][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if (li == 0) {
+                    const int c = co0 + nb * 16 + lg * 4 + e;
+                    sp[c] = a;
+                    sp[g.Cout + c] = q;
+                }
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
@@ -650,7 +717,7 @@ int launch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGe
 }
 
 template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
-int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGeo g, hipStream_t s) {
+int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGeo g, float* stats, hipStream_t s) {
     typedef CG<CPC, KS> G;
     g.tx = (g.X + TX - 1) / TX;
     g.ty = (g.Y + TY - 1) / TY;
@@ -666,13 +733,13 @@ int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, 
         attr_done = true;
     }
     hipLaunchKernelGGL((conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT>), dim3((unsigned)cols, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp, bias,
-                       y, g);
+                       y, g, stats);
     UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
     return UCFVIT_OK;
 }
 
 template <int TZT>
-int launch_fwd_mc(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, hipStream_t s) {
+int launch_fwd_mc(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, float* stats, hipStream_t s) {
     g.tx = (g.X + 1) / 2;
     g.ty = (g.Y + 7) / 8;
     g.tz = TZT;
@@ -685,7 +752,7 @@ int launch_fwd_mc(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, hipStream_t
         (void)hipFuncSetAttribute((const void*)conv3_fwd_mc_kernel<TZT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3_fwd_mc_kernel<TZT>), dim3((unsigned)cols, g.Cout / 32), dim3(CT), SMEM, s, x, wp, y, g);
+    hipLaunchKernelGGL((conv3_fwd_mc_kernel<TZT>), dim3((unsigned)cols, g.Cout / 32), dim3(CT), SMEM, s, x, wp, y, g, stats);
     UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
     return UCFVIT_OK;
 }
@@ -699,33 +766,48 @@ static int strip_mode() {          // UCFVIT_CONV_STRIP: 0 never, 1 (default) wh
     return flag;
 }
 
-template <int CPC, int KS, typename OutT>
-int dispatch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, const ConvGeo& g, hipStream_t s) {
-    const int nb16 = g.Cout / 16;
-    // multi-chunk 3x3x3 layers of the coarser levels (bf16 out, no bias, dense output, 32 k output channels, Z = 16 / 32 / 64): chunk-outer column kernel
-    if constexpr (CPC == 32 && KS == 3 && sizeof(OutT) == 2) {
-        if (g.Cin > 32 && !bias && g.Cout % 32 == 0 && g.cout_store == g.Cout && g.ldy == g.Cout && strip_mode() &&
-            (g.Z == 16 || g.Z == 32 || g.Z == 64)) {
-            const int64_t wgs = (int64_t)g.B * ((g.X + 1) / 2) * ((g.Y + 7) / 8) * (g.Cout / 32);
-            if (strip_mode() == 2 || wgs >= 512) {
-                if (g.Z == 16) return launch_fwd_mc<1>(x, wp, (bf16*)y, g, s);
-                if (g.Z == 32) return launch_fwd_mc<2>(x, wp, (bf16*)y, g, s);
-                return launch_fwd_mc<4>(x, wp, (bf16*)y, g, s);
-            }
-        }
+// which forward kernel serves a launch: 0 = one tile per workgroup, 1 = single-chunk column kernel, 2 = multi-chunk column kernel; TX, TY = its tile
+struct FwdPlan {
+    int kind, TX, TY;
+};
+static FwdPlan fwd_plan(const ConvGeo& g, int ksize, bool has_bias, bool out_bf16) {
+    const int cpc = g.Cin < 32 ? g.Cin : 32, nb16 = g.Cout / 16;
+    if (cpc == 32 && ksize == 3 && out_bf16 && g.Cin > 32 && !has_bias && g.Cout % 32 == 0 && g.cout_store == g.Cout && g.ldy == g.Cout && strip_mode() &&
+        (g.Z == 16 || g.Z == 32 || g.Z == 64)) {
+        const int64_t wgs = (int64_t)g.B * ((g.X + 1) / 2) * ((g.Y + 7) / 8) * (g.Cout / 32);
+        if (strip_mode() == 2 || wgs >= 512) return FwdPlan{2, 2, 8};
     }
-    // single-chunk inputs with at least two z tiles and enough (x, y) columns to fill the chip: the pipelined strip kernel
-    if (g.Cin == CPC && g.Z > 16 && strip_mode()) {
+    if (g.Cin == cpc && g.Z > 16 && strip_mode()) {
         const int64_t cols = (int64_t)g.B * ((g.X + 1) / 2) * ((g.Y + 7) / 8);
         if (strip_mode() == 2 || cols * (nb16 % 4 == 0 ? nb16 / 4 : nb16 % 2 == 0 ? nb16 / 2 : nb16) >= 512) {
-            if (nb16 % 4 == 0) return launch_fwd_strip<CPC, 4, 2, 4, KS, OutT>(x, wp, bias, y, g, s);
-            if (nb16 % 2 == 0) return launch_fwd_strip<CPC, 2, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
-            if constexpr (CPC == 32)
-                return launch_fwd_strip<CPC, 1, 2, 8, KS, OutT>(x, wp, bias, y, g, s);      // the 4 x 8 tile's prefetch would not fit in registers
-            else
-                return launch_fwd_strip<CPC, 1, 4, 8, KS, OutT>(x, wp, bias, y, g, s);
+            if (nb16 % 4 == 0) return FwdPlan{1, 2, 4};
+            if (nb16 % 2 == 0 || cpc == 32) return FwdPlan{1, 2, 8};      // (CPC 32, NB 1): the 4 x 8 tile's prefetch would not fit in registers
+            return FwdPlan{1, 4, 8};
         }
     }
+    return FwdPlan{0, 0, 0};
+}
+
+template <int CPC, int KS, typename OutT>
+int dispatch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, const ConvGeo& g, float* stats, hipStream_t s) {
+    const int nb16 = g.Cout / 16;
+    const FwdPlan pl = fwd_plan(g, KS, bias != nullptr, sizeof(OutT) == 2);
+    if constexpr (CPC == 32 && KS == 3 && sizeof(OutT) == 2) {
+        if (pl.kind == 2) {
+            if (g.Z == 16) return launch_fwd_mc<1>(x, wp, (bf16*)y, g, stats, s);
+            if (g.Z == 32) return launch_fwd_mc<2>(x, wp, (bf16*)y, g, stats, s);
+            return launch_fwd_mc<4>(x, wp, (bf16*)y, g, stats, s);
+        }
+    }
+    if (pl.kind == 1) {
+        if (nb16 % 4 == 0) return launch_fwd_strip<CPC, 4, 2, 4, KS, OutT>(x, wp, bias, y, g, stats, s);
+        if (nb16 % 2 == 0) return launch_fwd_strip<CPC, 2, 2, 8, KS, OutT>(x, wp, bias, y, g, stats, s);
+        if constexpr (CPC == 32)
+            return launch_fwd_strip<CPC, 1, 2, 8, KS, OutT>(x, wp, bias, y, g, stats, s);
+        else
+            return launch_fwd_strip<CPC, 1, 4, 8, KS, OutT>(x, wp, bias, y, g, stats, s);
+    }
+    UCF_CHECK_ARG(!stats, "ucfvit_conv3d_fwd: this launch has no statistics epilogue (ask ucfvit_conv3d_fwd_stats_rows first)");
     if (nb16 % 4 == 0) return launch_fwd<CPC, 4, 2, 4, KS, OutT>(x, wp, bias, y, g, s);
     if (nb16 % 2 == 0) return launch_fwd<CPC, 2, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
     return launch_fwd<CPC, 1, 2, 8, KS, OutT>(x, wp, bias, y, g, s);
@@ -798,17 +880,30 @@ int launch_wgrad(const bf16* x, const bf16* dy, float* dw, float* ws, ConvGeo g,
 
 // x [B][X][Y][Z][Cin] bf16, w_packed [Cin/CPC][NTS][Cout][32] bf16, bias fp32 [Cout] or NULL -> y[voxel * ldy + co] for co < cout_store
 extern "C" int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z,
-                                 int64_t Cin, int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate, void* stream) {
+                                 int64_t Cin, int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate,
+                                 float* stats_partial, void* stream) {
     if (int rc = conv_check("ucfvit_conv3d_fwd", x, w_packed, y, B, X, Y, Z, Cin, Cout, ksize)) return rc;
     UCF_CHECK_ARG(cout_store > 0 && cout_store <= Cout && ldy >= cout_store && ldy < (1ll << 31), "ucfvit_conv3d_fwd: need 0 < cout_store <= Cout, ldy >= cout_store");
     UCF_CHECK_ARG(out_dtype == UCFVIT_BF16 || out_dtype == UCFVIT_F32, "ucfvit_conv3d_fwd: bad out_dtype %d", out_dtype);
     ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, (int)ldy, (int)cout_store, accumulate ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
+    UCF_CHECK_ARG(!stats_partial || (out_dtype == UCFVIT_BF16 && !accumulate && cout_store == Cout && ldy == Cout),
+                  "ucfvit_conv3d_fwd: statistics need a dense bf16 output without accumulation");
     CONV_SWITCH(Cin, ksize, {
-        if (out_dtype == UCFVIT_BF16) return dispatch_fwd<CPC_, KS_, bf16>((const bf16*)x, (const bf16*)w_packed, bias, (bf16*)y, g, s);
-        return dispatch_fwd<CPC_, KS_, float>((const bf16*)x, (const bf16*)w_packed, bias, (float*)y, g, s);
+        if (out_dtype == UCFVIT_BF16) return dispatch_fwd<CPC_, KS_, bf16>((const bf16*)x, (const bf16*)w_packed, bias, (bf16*)y, g, stats_partial, s);
+        return dispatch_fwd<CPC_, KS_, float>((const bf16*)x, (const bf16*)w_packed, bias, (float*)y, g, stats_partial, s);
     });
     return UCFVIT_OK;
+}
+
+// rows per batch element of the statistics partials [B][rows][2][Cout] that ucfvit_conv3d_fwd writes for this launch (dense bf16 output, no
+// accumulation), 0 when the kernel that serves it has no statistics epilogue (the caller then runs ucfvit_instnorm_cl_stats on the output)
+extern "C" int64_t ucfvit_conv3d_fwd_stats_rows(int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin, int64_t Cout, int ksize, int has_bias) {
+    if (!(Cin == 8 || Cin == 16 || (Cin > 0 && Cin % 32 == 0)) || Cout <= 0 || Cout % 16 || !(ksize == 1 || ksize == 3)) return 0;
+    ConvGeo g{(int)B, (int)X, (int)Y, (int)Z, (int)Cin, (int)Cout, 0, 0, 0, 0, (int)Cout, (int)Cout, 0};
+    const FwdPlan pl = fwd_plan(g, ksize, has_bias != 0, true);
+    if (pl.kind == 0) return 0;
+    return (int64_t)((X + pl.TX - 1) / pl.TX) * ((Y + pl.TY - 1) / pl.TY) * 4;
 }
 
 // number of fp32 values of the packed weight gradient [Cout/(16 MB)][Cin/CPC][taps][16 MB][16 NBK] and bytes of scratch for the partials

@@ -355,6 +355,50 @@ __global__ __launch_bounds__(64) void incl_stats_final(const bf16* __restrict__ 
         rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
+// first stage of that fold when there are many partial rows (a full-resolution layer writes 32768 per batch element): workgroup (g, b)
+// adds the rows [g rpg, (g + 1) rpg) of [B][rows][C2] with coalesced reads (a thread owns a column, 256 / C2 rows in flight) -> [B][G][C2]
+__global__ __launch_bounds__(NT) void incl_stats_fold1(const float* __restrict__ part, float* __restrict__ out, int rows, int C2, int rpg) {
+    __shared__ float red[NT];
+    const int64_t b = blockIdx.y;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int lo = g * rpg, hi = min(rows, lo + rpg);
+    for (int c0 = 0; c0 < C2; c0 += NT) {                       // C2 <= 256: one trip
+        const int w = min(C2 - c0, NT);                         // columns of this trip (a power of two: C2 = 2 C)
+        const int col = threadIdx.x % w, rl = threadIdx.x / w, rs = NT / w;
+        float s = 0.f;
+        for (int r = lo + rl; r < hi; r += rs) s += part[(b * rows + r) * C2 + c0 + col];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < w) {
+            float t = 0.f;
+            for (int k = 0; k < rs; ++k) t += red[k * w + threadIdx.x];
+            out[(b * G + g) * C2 + c0 + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+// the same fold for UNSHIFTED partial sums [B][rows][2][C] (sum, sum of squares) written by the convolution kernels' statistics epilogue
+__global__ __launch_bounds__(64) void incl_stats_fold(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int64_t S,
+                                                      int C, int rows, float eps) {
+    const int64_t b = blockIdx.x / C;
+    const int c = blockIdx.x % C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 64) {
+        s1 += part[(b * rows + r) * 2 * C + c];
+        s2 += part[(b * rows + r) * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double m = s1 / (double)S;
+        const double var = fmax(s2 / (double)S - m * m, 0.0);
+        mean[blockIdx.x] = (float)m;
+        rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
 template <bool RES>
 __global__ __launch_bounds__(NT) void incl_apply(const bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                  const bf16* __restrict__ res, bf16* __restrict__ y, int64_t S, int C, float slope) {
@@ -830,5 +874,39 @@ extern "C" int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void
     hipLaunchKernelGGL(incl_bwd2_apply, g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, (const bf16*)x2, mean2, rstd2, mm,
                        (bf16*)dx, (bf16*)dx2, S, (int)C, slope, ldg8, (int)(B * C));
     UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd2");
+    return UCFVIT_OK;
+}
+
+// mean / rstd [B][C] from the partial sums [B][rows][2][C] of ucfvit_conv3d_fwd's statistics epilogue (S = voxels per batch element)
+extern "C" int ucfvit_instnorm_cl_stats_fold(const float* partial, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, int64_t rows, float eps,
+                                             void* workspace, void* stream) {      // workspace: B * 256 * 2 C floats (may be NULL: single stage)
+    UCF_CHECK_ARG(partial && mean && rstd && B > 0 && S > 0 && C > 0 && rows > 0 && B * C < (1ll << 31) && rows < (1ll << 31),
+                  "ucfvit_instnorm_cl_stats_fold: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows > 512 && workspace && (C & (C - 1)) == 0) {
+        // two stages: 128..256 row groups per batch element first (coalesced), then the per-channel fold over the groups
+        const int G = (int)((rows + 255) / 256) > 256 ? 256 : (int)((rows + 255) / 256);
+        const int rpg = (int)((rows + G - 1) / G);
+        hipLaunchKernelGGL(incl_stats_fold1, dim3(G, (unsigned)B), dim3(NT), 0, s, partial, (float*)workspace, (int)rows, (int)(2 * C), rpg);
+        hipLaunchKernelGGL(incl_stats_fold, dim3((unsigned)(B * C)), dim3(64), 0, s, (const float*)workspace, mean, rstd, S, (int)C, G, eps);
+    } else {
+        hipLaunchKernelGGL(incl_stats_fold, dim3((unsigned)(B * C)), dim3(64), 0, s, partial, mean, rstd, S, (int)C, (int)rows, eps);
+    }
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_stats_fold");
+    return UCFVIT_OK;
+}
+
+// apply pass alone, statistics given: y = lrelu((x - mean) rstd [+ res], slope)
+extern "C" int ucfvit_instnorm_cl_apply(const void* x, const void* res, void* y, const float* mean, const float* rstd, int64_t B, int64_t S, int64_t C,
+                                        float slope, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_apply", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(y && mean && rstd && ucf_is_aligned16(y) && (!res || ucf_is_aligned16(res)), "ucfvit_instnorm_cl_apply: bad pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+    if (res)
+        hipLaunchKernelGGL((incl_apply<true>), g, dim3(NT), 0, s, (const bf16*)x, mean, rstd, (const bf16*)res, (bf16*)y, S, (int)C, slope);
+    else
+        hipLaunchKernelGGL((incl_apply<false>), g, dim3(NT), 0, s, (const bf16*)x, mean, rstd, (const bf16*)x, (bf16*)y, S, (int)C, slope);
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_apply");
     return UCFVIT_OK;
 }
