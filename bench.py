@@ -46,8 +46,10 @@ WORKLOADS = {
     # SURVEY §8f row 1 (not the headline metric): the reference's imagenet config shape, adaptive_patching with fixed_length 196 and
     # use_adaptive_pos_emb (configs/imagenet/classification/base_config.yaml:46-49); input = token sequences [B, 3, 196, 256] + seq_ps
     "vit_l16_adaptive196": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166, adaptive=196),
-    # 256 * 49 = 12544 encoder rows = 49 M-tiles, 256 * 196 = 50176 decoder rows = 196 M-tiles
-    "mae_vit_l16_224": dict(kind="mae", img=224, patch=16, dim=1024, depth=24, heads=16, batch=256, mask_ratio=0.75,
+    # 334 * 49 = 16366 encoder rows -> 64 M-tiles of 256, 334 * 196 = 65464 decoder rows -> 256 M-tiles: every GEMM of the step (N = 1024 ... 4096
+    # encoder, 512 ... 2048 decoder) is a whole number of rounds of 256 CUs (batch 256: 49 / 196 M-tiles, 77 % of the last round idle; measured
+    # 5442 -> 6086 images/s, batch 336 — one tile more — 5233)
+    "mae_vit_l16_224": dict(kind="mae", img=224, patch=16, dim=1024, depth=24, heads=16, batch=334, mask_ratio=0.75,
                             dec_dim=512, dec_depth=8, dec_heads=16),
     # per-GPU batch 2 = the reference's basic_ct batch size (configs/basic_ct/unetr/base_config.yaml:82)
     "unetr_enc_512x512x128": dict(kind="unetr", vol=(512, 512, 128), patch=16, dim=768, depth=12, heads=12, batch=2),
