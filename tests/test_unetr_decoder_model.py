@@ -17,10 +17,10 @@ import torch
 DEV = "cuda"
 
 
-def _model(img, embed_dim=96, depth=4, heads=3, fs=16, seed=0):
+def _model(img, embed_dim=96, depth=4, heads=3, fs=16, seed=0, in_chans=1):
     from UCF_VIT.simple.arch import UNETR
     torch.manual_seed(seed)
-    m = UNETR(img_size=img, patch_size=16, in_chans=1, embed_dim=embed_dim, depth=depth, num_heads=heads, class_token=False, twoD=False,
+    m = UNETR(img_size=img, patch_size=16, in_chans=in_chans, embed_dim=embed_dim, depth=depth, num_heads=heads, class_token=False, twoD=False,
               num_classes=4, linear_decoder=False, feature_size=fs, skip_connection=True)
     return m.to(DEV)
 
@@ -152,3 +152,23 @@ def test_unetr_whole_model_vs_cpu_oracle():
     rel = ((logits.float().cpu() - logits_ref).norm() / logits_ref.norm()).item()
     assert rel < 3e-2, rel
     assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
+
+
+@pytest.mark.gpu
+def test_unetr_hip_decoder_multi_channel_input():
+    """in_chans = 3 (<= 8: zero-padded to the 8-channel MFMA operand; the weights of encoder1's convolutions are padded with zero input channels):
+    logits and loss of the HIP decoder against the torch/MIOpen decoder, gradients of encoder1's convolutions have the parameter's own shape"""
+    img = [32, 32, 32]
+    m = _model(img, seed=5, in_chans=3)
+    m.set_compute_dtype(torch.bfloat16)
+    assert m.hip_decoder()
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, *img, generator=g).to(DEV)
+    lab = torch.randint(0, 4, (2, *img), generator=g).to(DEV)
+    lo_h, loss_h, g_h = _run(m, x, lab, "hip")
+    lo_t, loss_t, g_t = _run(m, x, lab, "torch")
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+    assert rel(lo_h, lo_t) < 3e-2 and abs(loss_h - loss_t) < 2e-2 * abs(loss_t)
+    for n in ("encoder1.layer.conv1.conv.weight", "encoder1.layer.conv3.conv.weight"):
+        assert g_h[n].shape == g_t[n].shape and g_h[n].shape[1] == 3
+        assert rel(g_h[n], g_t[n]) < 0.25
