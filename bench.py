@@ -39,17 +39,20 @@ for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT):
         sys.path.insert(0, p)
 
 WORKLOADS = {
-    # 166*197 = 32702 rows -> 128 M-tiles of 256: every GEMM fills whole rounds of 256 CUs
-    "vit_l16_224": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166),
-    "vit_b16_224": dict(kind="vit", img=224, patch=16, dim=768, depth=12, heads=12, classes=1000, batch=332),   # 65404 rows -> 256 M-tiles
+    # Per-GPU batches are chosen so that the token rows fill a multiple of 64 M-tiles of 256 rows: every GEMM of the step (3 ... 16 N-tiles) is then
+    # a whole number of rounds of the 256 CUs (one M-tile more costs a whole extra round: MAE 334 -> 336 images loses 14 %).  Among those batches the
+    # large ones win: the per-step constants (AdamW over 304 M parameters = 1.8 ms, weight-shadow transposes, launch tails) are paid once per step and
+    # a data-parallel gradient all-reduce has 4x the backward time to hide in — 288 GB of HBM hold them easily (ViT-L at 665 images: see DESIGN §6a).
+    # 665*197 = 131005 rows -> 512 M-tiles (166: 128 M-tiles, 2393 images/s; 332: 2491; 498: 2536; 665: 2554 on the same box)
+    "vit_l16_224": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=665),
+    "vit_b16_224": dict(kind="vit", img=224, patch=16, dim=768, depth=12, heads=12, classes=1000, batch=1330),   # 262010 rows -> 1024 M-tiles
     "vit_tiny16_256": dict(kind="vit", img=256, patch=16, dim=192, depth=12, heads=3, classes=2, batch=256),
     # SURVEY §8f row 1 (not the headline metric): the reference's imagenet config shape, adaptive_patching with fixed_length 196 and
     # use_adaptive_pos_emb (configs/imagenet/classification/base_config.yaml:46-49); input = token sequences [B, 3, 196, 256] + seq_ps
-    "vit_l16_adaptive196": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=166, adaptive=196),
-    # 334 * 49 = 16366 encoder rows -> 64 M-tiles of 256, 334 * 196 = 65464 decoder rows -> 256 M-tiles: every GEMM of the step (N = 1024 ... 4096
-    # encoder, 512 ... 2048 decoder) is a whole number of rounds of 256 CUs (batch 256: 49 / 196 M-tiles, 77 % of the last round idle; measured
-    # 5442 -> 6086 images/s, batch 336 — one tile more — 5233)
-    "mae_vit_l16_224": dict(kind="mae", img=224, patch=16, dim=1024, depth=24, heads=16, batch=334, mask_ratio=0.75,
+    "vit_l16_adaptive196": dict(kind="vit", img=224, patch=16, dim=1024, depth=24, heads=16, classes=1000, batch=665, adaptive=196),
+    # 1002 * 49 = 49098 encoder rows -> 192 M-tiles of 256, 1002 * 196 = 196392 decoder rows -> 768 M-tiles (batch 256: 49 / 196 M-tiles, 77 % of
+    # the last round idle: 5442 images/s; 334: 6086; 336 — one tile more — 5233; 668: 6435; 1002: 6561)
+    "mae_vit_l16_224": dict(kind="mae", img=224, patch=16, dim=1024, depth=24, heads=16, batch=1002, mask_ratio=0.75,
                             dec_dim=512, dec_depth=8, dec_heads=16),
     # per-GPU batch 2 = the reference's basic_ct batch size (configs/basic_ct/unetr/base_config.yaml:82)
     "unetr_enc_512x512x128": dict(kind="unetr", vol=(512, 512, 128), patch=16, dim=768, depth=12, heads=12, batch=2),
