@@ -641,28 +641,27 @@ __global__ __launch_bounds__(CT) void conv_wgrad_kernel(const bf16* __restrict__
 // a channel slice of a wider channels-last buffer (row stride lds8 sixteen-byte units): the up-sampled map is written straight into the
 // first half of the concatenation the next residual block reads, and its gradient is gathered straight out of that block's input gradient.
 __global__ __launch_bounds__(CT) void d2s_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int Xi, int Yi, int Zi, int C,
-                                                 int to_space, int64_t lds8, const bf16* __restrict__ skip, int Cs) {
-    // the thread index walks the vectors of the space-side ROW that this launch touches: C / 8 of the up-sampled map, then (to_space with a
-    // skip) Cs / 8 of the skip connection, so a whole row of the concatenation is written by consecutive lanes (full cache lines)
-    const int cv = C / 8, cvt = cv + (skip ? Cs / 8 : 0);
-    const int64_t total = (int64_t)B * Xi * Yi * Zi * 8 * cvt;
-    for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < total; i += (int64_t)gridDim.x * CT) {
-        int64_t r = i;
-        const int c = (int)(r % cvt);
-        r /= cvt;
-        const int64_t vox = r;                                  // linear voxel index of the space tensor
-        const int64_t k = vox * lds8 + c;
+                                                 int to_space, int64_t lds8, const bf16* __restrict__ skip, int Cs, int cvt_shift) {
+    // a thread owns one 16-byte vector of a space-side voxel ROW: C / 8 vectors of the up-sampled map, then (to_space with a skip) Cs / 8 of the
+    // skip connection, so a whole row of the concatenation is written by consecutive lanes (full cache lines).  The row length cvt is a power of
+    // two (cvt_shift): voxel and vector index are a shift and a mask of the thread index, the voxel coordinates three 32-bit divisions.
+    const int cv = C / 8, cvt = 1 << cvt_shift;
+    const unsigned nvox = (unsigned)B * (2u * Xi) * (2u * Yi) * (2u * Zi);
+    const unsigned vpb = CT >> cvt_shift;                                  // voxels per workgroup step
+    const int c = threadIdx.x & (cvt - 1);
+    for (unsigned vox = blockIdx.x * vpb + (threadIdx.x >> cvt_shift); vox < nvox; vox += gridDim.x * vpb) {
+        const int64_t k = (int64_t)vox * lds8 + c;
         if (c >= cv) {                                          // skip half of the concatenation
-            reinterpret_cast<u32x4*>(dst)[k] = reinterpret_cast<const u32x4*>(skip)[vox * (Cs / 8) + (c - cv)];
+            reinterpret_cast<u32x4*>(dst)[k] = reinterpret_cast<const u32x4*>(skip)[(int64_t)vox * (Cs / 8) + (c - cv)];
             continue;
         }
-        const int zo = (int)(r % (2 * Zi));
-        r /= 2 * Zi;
-        const int yo = (int)(r % (2 * Yi));
-        r /= 2 * Yi;
-        const int xo = (int)(r % (2 * Xi));
-        const int64_t b = r / (2 * Xi);
-        const int64_t vin = ((b * Xi + (xo >> 1)) * Yi + (yo >> 1)) * Zi + (zo >> 1);
+        unsigned r = vox;
+        const unsigned zo = r % (2u * Zi);
+        r /= 2u * Zi;
+        const unsigned yo = r % (2u * Yi);
+        r /= 2u * Yi;
+        const unsigned xo = r % (2u * Xi), b = r / (2u * Xi);
+        const int64_t vin = (((int64_t)b * Xi + (xo >> 1)) * Yi + (yo >> 1)) * Zi + (zo >> 1);
         const int64_t j = (vin * 8 + ((xo & 1) * 4 + (yo & 1) * 2 + (zo & 1))) * cv + c;
         if (to_space)
             reinterpret_cast<u32x4*>(dst)[k] = reinterpret_cast<const u32x4*>(src)[j];
@@ -949,11 +948,16 @@ extern "C" int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int
     UCF_CHECK_ARG(ld_space >= C && ld_space % 8 == 0, "ucfvit_depth_to_space2: ld_space must be a multiple of 8 and >= C");
     UCF_CHECK_ARG(ucf_is_aligned16(src) && ucf_is_aligned16(dst), "ucfvit_depth_to_space2: operands must be 16-byte aligned");
     if (skip) UCF_CHECK_ARG(to_space == 1 && Cs > 0 && Cs % 8 == 0 && ld_space >= C + Cs && ucf_is_aligned16(skip), "ucfvit_depth_to_space2: bad skip operand");
-    const int64_t total = B * Xi * Yi * Zi * (C + (skip ? Cs : 0));       // 16-byte pieces
+    const int64_t cvt = (C + (skip ? Cs : 0)) / 8;                           // 16-byte vectors per voxel row handled by this launch
+    UCF_CHECK_ARG(cvt <= CT && (cvt & (cvt - 1)) == 0, "ucfvit_depth_to_space2: (C + Cs) / 8 must be a power of two <= 256 (got %lld)", (long long)cvt);
+    UCF_CHECK_ARG(B * Xi * Yi * Zi * 8 < (1ll << 32), "ucfvit_depth_to_space2: more than 2^32 output voxels");
+    int shift = 0;
+    while ((1ll << shift) < cvt) ++shift;
+    const int64_t total = B * Xi * Yi * Zi * 8 * cvt;                        // 16-byte pieces
     int64_t blocks = (total + CT - 1) / CT;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(d2s_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, (int)B, (int)Xi,
-                       (int)Yi, (int)Zi, (int)C, to_space, ld_space / 8, (const bf16*)skip, (int)Cs);
+                       (int)Yi, (int)Zi, (int)C, to_space, ld_space / 8, (const bf16*)skip, (int)Cs, shift);
     UCF_LAUNCH_CHECK("ucfvit_depth_to_space2");
     return UCFVIT_OK;
 }
