@@ -123,3 +123,19 @@ def test_wgrad_queue_flushes_the_last_group_in_pairs_under_data_parallel(monkeyp
     q2.listeners.append(weakref.WeakMethod(owner.poke))
     one_pass(q2, 24)
     assert launches == [16] * 6                                   # first pass of a fresh queue: the count is not known yet
+
+
+def test_unetr_decoder_flops_and_hip_decoder_rule():
+    """host logic of the whole-UNETR workload: the decoder's forward FLOPs at 512 x 512 x 128 / feature_size 16 (4.04 TF: 3.85 TF of 3x3x3
+    convolutions, the rest transposed / pointwise layers), and the rule that sends a configuration to the HIP convolution kernels"""
+    import bench
+    from UCF_VIT.simple.unetr_blocks import hip_decoder_supported
+    f = bench.unetr_decoder_fwd_flops(8192, 768, 16, 4)
+    assert abs(f / 1e12 - 4.035) < 0.01
+    # doubling the feature size quadruples the convolution work (channels in x channels out) of all but the input layer
+    assert 3.5 < bench.unetr_decoder_fwd_flops(8192, 768, 32, 4) / f < 4.0
+    assert hip_decoder_supported(3, 1, 768, 16) and hip_decoder_supported(3, 3, 768, 32) and hip_decoder_supported(3, 8, 96, 64)
+    assert not hip_decoder_supported(2, 1, 768, 16)            # 2-D models keep the torch/MIOpen convolutions (+ the fused N C H W norm kernels)
+    assert not hip_decoder_supported(3, 9, 768, 16)            # more input channels than the zero-padded 8-channel operand
+    assert not hip_decoder_supported(3, 1, 768, 48)            # 48, 96, 192 ... channels: not powers of two (the channels-last norm kernels)
+    assert not hip_decoder_supported(3, 1, 768, 16, kernel_size=5)
