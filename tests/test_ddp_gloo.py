@@ -214,3 +214,83 @@ def test_hip_data_parallel_two_ranks_share_one_gpu():
     for rank, bad, same, flat in res:
         assert not bad, f"rank {rank}: gradient mismatch in {bad}"
         assert same and flat
+
+
+def _hip_dp_unetr_worker(rank, world, port, q):
+    """whole UNETR with the convolutional decoder on the HIP kernels: the decoder's weight gradients come back from autograd functions
+    (UCF_VIT/_hip/conv.py) as freshly allocated tensors, the encoder's are written into the flat buffer by the kernels: both kinds must come
+    out as the mean over the ranks, inside the flat buffer the optimizer and the buckets use"""
+    for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from UCF_VIT.simple.arch import UNETR
+        from UCF_VIT._hip import functional as HF
+        from UCF_VIT._hip.ddp import HipDataParallel
+        from UCF_VIT.utils.misc import configure_optimizer
+        from det_weights import det_state_dict, det_tensor
+        img = [32, 32, 32]
+        kw = dict(img_size=img, patch_size=16, in_chans=1, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False, num_classes=4,
+                  linear_decoder=False, feature_size=16, skip_connection=True)
+        m = UNETR(**kw)
+        sd = det_state_dict(m, 400)
+        m.load_state_dict(sd)
+        m = m.to("cuda:0")
+        assert m.hip_decoder()
+        xs = [det_tensor((1, 1, *img), 410 + r).abs() for r in range(world)]
+        labs = [(x[:, 0] * 3).long().clamp_(0, 3) for x in xs]
+        ref = UNETR(**kw)
+        ref.load_state_dict(sd)
+        ref = ref.to("cuda:0")
+        exp = None
+        for r in range(world):
+            ref.zero_grad()
+            HF.dice_ce(ref(xs[r].to("cuda:0"), None), labs[r].to("cuda:0")).backward()
+            HF.flush_wgrads()
+            g = [p.grad.detach().clone() for p in ref.parameters()]
+            exp = g if exp is None else [a + b for a, b in zip(exp, g)]
+        ddp = HipDataParallel(m, bucket_mb=0.05)
+        opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 0.0)
+        HF.dice_ce(ddp(xs[rank].to("cuda:0"), None), labs[rank].to("cuda:0")).backward()
+        torch.cuda.synchronize()
+        from conftest import rel_err
+        bad = [k for (k, p), e in zip(m.named_parameters(), exp) if p.grad is None or rel_err(p.grad, e / world) > 1e-3]
+        inflat = all(p.grad.data_ptr() == m._ucf_store.flat_g.data_ptr() + 4 * o for p, o in zip(m._ucf_store.params, m._ucf_store.offsets)
+                     if p.grad is not None)
+        n_dec = sum(k.startswith(("encoder", "decoder", "out.")) for k, _ in m.named_parameters())
+        opt.step()
+        w = m._ucf_store.flat_p.detach().cpu()
+        w0 = w.clone()
+        dist.broadcast(w0, 0)
+        q.put((rank, bad, inflat, n_dec, bool(torch.equal(w, w0))))
+        dist.barrier()
+    except Exception as e:          # report instead of letting the parent sit out its queue timeout on a GPU box
+        import traceback
+        q.put((rank, ["EXCEPTION " + repr(e) + " " + traceback.format_exc()[-1200:]], False, -1, False))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_data_parallel_whole_unetr_with_hip_decoder_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_dp_unetr_worker, args=(r, 2, 29576, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(2):
+        res.append(q.get(timeout=240))
+        if res[-1][3] == -1:                       # a rank raised: the other one hangs in a collective
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"rank {res[-1][0]}: {res[-1][1]}")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, inflat, n_dec, same in res:
+        assert not bad, f"rank {rank}: gradient mismatch in {bad}"
+        assert inflat and n_dec == 33 and same
