@@ -16,6 +16,8 @@
 
 #include "common.h"
 
+int ucfvit_gemm_stagger_try(const ucfvit_gemm_desc* d, hipStream_t s);   // gemm_stagger.hip
+
 namespace {
 
 constexpr int BK2 = 64;
@@ -1188,6 +1190,10 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
         // straight-line epilogues for the shapes of the training step (see EPI_* above); everything else is generic
         if (!generic_epilogue_only() && p.splits == 1 && !ep.slab && !d->accumulate && d->N >= 8) {
             const int K_ = (int)d->K;
+            // the epilogue hidden under the partner group's K loop (gemm_stagger.hip) where that kernel applies
+            const int rs = ucfvit_gemm_stagger_try(d, s);
+            if (rs == 1) return UCFVIT_OK;
+            if (rs < 0) return rs;
             if (ep.act == UCFVIT_ACT_NONE && !ep.residual && !ep.aux_out)
                 return launch3g<LA, LB, OutT, EPI_PLAIN, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_NONE && ep.residual && !ep.aux_out)
