@@ -109,7 +109,9 @@ typedef struct ucfvit_gemm_desc {
                               * used by every launch of ONE stream.  With it the persistent 256x256 kernel hands its output tiles out through
                               * device-scope atomic counters (work-conserving when another kernel — an RCCL collective overlapping backward —
                               * holds some of the CUs: workgroups that start late find the list empty instead of owning a share of it) and
-                              * leaves the state zeroed.  Results do not depend on it (every tile is computed by one workgroup either way).
+                              * leaves the state zeroed.  Results do not depend on the tile order (every tile is computed by one workgroup either way); a launch
+                              * with sched_state always takes the ping-pong kernel, a launch without it may take the staggered kernel (csrc/gemm_stagger.hip),
+                              * whose rows 128-255 of a tile accumulate over K in a rotated — equally fixed — order: the same values up to fp32 summation order.
                               * NULL: static tile order. */
 } ucfvit_gemm_desc;
 #define UCFVIT_GEMM_SCHED_BYTES 1024

@@ -530,7 +530,8 @@ torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[2])
 
 def test_gemm_dynamic_tile_schedule_is_result_neutral(tmp_path):
     """desc.sched_state (tiles of the persistent 256x256 kernel handed out by atomic counters, for launches that share the GPU with an
-    RCCL collective): bitwise the results of the static order for every epilogue kind and the grouped weight gradient, with the grid
+    RCCL collective): bitwise the results of the static order OF THE SAME KERNEL (UCFVIT_GEMM_STAGGER=0: without sched_state some
+    launches would take the staggered kernel, whose accumulation order differs) for every epilogue kind and the grouped weight gradient, with the grid
     capped at 256 / 240 / 200 workgroups (UCFVIT_GEMM_CUS: what a collective holding 16 / 56 CUs leaves), and the schedule state is
     all zeros again after every launch."""
     import os
@@ -543,7 +544,7 @@ def test_gemm_dynamic_tile_schedule_is_result_neutral(tmp_path):
     for dyn, cus in (("0", "256"), ("1", "256"), ("1", "240"), ("1", "200"), ("0", "200")):
         f = tmp_path / f"o_{dyn}_{cus}.pt"
         r = subprocess.run([sys.executable, str(script), root, str(f)], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, UCFVIT_GEMM_DYNAMIC=dyn, UCFVIT_GEMM_CUS=cus))
+                           env=dict(os.environ, UCFVIT_GEMM_DYNAMIC=dyn, UCFVIT_GEMM_CUS=cus, UCFVIT_GEMM_STAGGER="0"))
         assert r.returncode == 0, r.stderr[-2000:]
         res[(dyn, cus)] = torch.load(f, weights_only=True)
     ref = res[("0", "256")]
