@@ -156,10 +156,13 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, poll_s=0.2):
     """`python bench.py --gpus N` without a launcher: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, like
-    torch.distributed.run does) BEFORE this process has touched the GPU, wait for all, relay rank 0's JSON line.  The parent never
-    initialises HIP and never replaces itself (children are ordinary subprocesses)."""
+    torch.distributed.run does) BEFORE this process has touched the GPU, relay rank 0's JSON line.  The parent never initialises HIP and
+    never replaces itself (children are ordinary, freshly started subprocesses).  Every child is polled: the first one that exits non-zero
+    (out of memory, RCCL initialisation failure, GPU fault) gets its siblings terminated — they would otherwise sit in a collective until
+    the process-group timeout, holding their GPUs — and the parent exits non-zero naming (rank, exit code)."""
+    import threading
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):
@@ -167,14 +170,37 @@ def launch_ranks(n, argv):
                    MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))   # stderr of every rank is inherited
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)    # rank 0's pipe must be drained while we poll
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc is not None and rc != 0:
+                failed = (r, rc)
+                break
+        else:
+            time.sleep(poll_s)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:                       # exactly the children started above, by handle (never by pattern)
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        raise SystemExit(f"bench.py: rank {failed[0]} exited with code {failed[1]}; the other ranks were stopped "
+                         f"(exit codes {[p.returncode for p in procs]})")
+    reader.join(timeout=10.0)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0])
         sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
 
 
 # --------------------------------------------------------------------------------------------------------------- in-process profiler
@@ -329,7 +355,26 @@ def cpu_baseline(wname, w, steps=5):
 
 
 # --------------------------------------------------------------------------------------------------------------- workloads
-def build_workload(args, w, dev, rank):
+def setup_parallel_groups(args, w, world, rank):
+    """--sp / --tp: the process groups of the reference's Hybrid-OP layout (utils/misc.init_par_groups = reference utils/misc.py:129-238;
+    the entry scripts build them at training_scripts/train_masked_fsdp.py:219-223) and, for sequence parallelism, the 2-D Ulysses x ring
+    view of every sequence-parallel group.  Collective over the whole world: every rank calls it."""
+    sp, tp = args.sp, args.tp
+    if sp == 1 and tp == 1:
+        return None
+    from UCF_VIT.utils.misc import init_par_groups
+    dp = world // (sp * tp)
+    seq_g, ddp_g, tp_g, _, _, _ = init_par_groups(rank, dp, tp, sp, dp, 1)
+    par = dict(sp=sp, tp=tp, dp=dp, dp_index=rank // (sp * tp), ddp_group=ddp_g, tp_group=tp_g, spg=None, grid="")
+    if sp > 1:
+        from UCF_VIT.fsdp.seq_parallel import make_seq_parallel_groups
+        lists = [[i * tp * sp + s_ * tp + t for s_ in range(sp)] for i in range(dp) for t in range(tp)]      # init_par_groups' "sp" lists
+        par["spg"] = make_seq_parallel_groups(lists, w["heads"], ulysses_size=args.ulysses or None)
+        par["grid"] = f"({par['spg'].pr}x{par['spg'].pu})"
+    return par
+
+
+def build_workload(args, w, dev, rank, par=None):
     """-> (net-able model, step closure factory inputs): returns (model, make_step) where make_step(net, opt, sch) -> step()"""
     import torch
     from UCF_VIT.utils.fused_attn import FusedAttn
@@ -386,11 +431,18 @@ def build_workload(args, w, dev, rank):
             return step
         desc = "MAE train step (mask 0.75 + gather, 24-block encoder on 49 tokens, 8 x 512 decoder on 196, MSE; fwd+bwd+AdamW), synthetic images resident in HBM"
         return model, make_step, B, desc, 0.05
-    from UCF_VIT.simple.arch import UNETR
     vol = list(w["vol"])
-    model = UNETR(img_size=vol, patch_size=w["patch"], in_chans=1, embed_dim=w["dim"], depth=w["depth"], num_heads=w["heads"],
-                  class_token=False, twoD=False, num_classes=4, linear_decoder=False, feature_size=16, skip_connection=True,
-                  FusedAttn_option=FusedAttn.HIP)
+    ukw = dict(img_size=vol, patch_size=w["patch"], in_chans=1, embed_dim=w["dim"], depth=w["depth"], num_heads=w["heads"],
+               class_token=False, twoD=False, num_classes=4, linear_decoder=False, feature_size=16, skip_connection=True,
+               FusedAttn_option=FusedAttn.HIP)
+    if par is None:
+        from UCF_VIT.simple.arch import UNETR
+        model = UNETR(**ukw)
+    else:
+        from UCF_VIT.fsdp.arch import UNETR
+        model = UNETR(seq_par_size=par["sp"], seq_par_group=par["spg"], tensor_par_size=par["tp"], tensor_par_group=par["tp_group"], **ukw)
+        # every rank of a sequence- / tensor-parallel group works on the SAME volumes: the data stream is seeded per data-parallel replica
+        g = torch.Generator().manual_seed(1234 + par["dp_index"])
     if w.get("decoder"):
         from UCF_VIT._hip import functional as HF
         model = model.to(dev)
@@ -440,6 +492,8 @@ def dry_run(args, world, rank):
     the barrier-bracketed timed region, MAX over ranks, one JSON line from rank 0.  The line is marked "dry_run" and has no value."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("UCFVIT_BENCH_DRY_FAIL_RANK") == str(rank):      # rehearsal of a rank that dies before the rendezvous
+        raise SystemExit(3)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
@@ -471,7 +525,16 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    # BASELINE config 5 ("hybrid-op sequence-parallel across 8 GPUs"): --gpus N = dp x sp (or dp x tp) ranks laid out like the reference's
+    # init_par_groups (utils/misc.py:129-238): rank = dp_index * (tp * sp) + sp_index * tp + tp_index.  UNETR workloads only.
+    ap.add_argument("--sp", type=int, default=1, help="sequence-parallel group size (UNETR workloads; the token sequence is sharded)")
+    ap.add_argument("--ulysses", type=int, default=0, help="all-to-all factor P_u of the 2-D Ulysses x ring layout (default gcd(heads, sp))")
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel (Hybrid-OP head / hidden shard) group size (UNETR workloads)")
     args = ap.parse_args()
+    if args.sp < 1 or args.tp < 1 or (args.sp > 1 and args.tp > 1) or args.gpus % (args.sp * args.tp):
+        raise SystemExit("bench.py: --gpus must be a multiple of --sp or --tp (sequence and tensor parallelism are not combined inside one Block)")
+    if (args.sp > 1 or args.tp > 1) and WORKLOADS[args.workload]["kind"] != "unetr":
+        raise SystemExit("bench.py: --sp / --tp apply to the UNETR workloads (BASELINE config 5)")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args.gpus, sys.argv[1:])      # nothing below has run: this process has not touched the GPU
@@ -505,12 +568,15 @@ def main():
     w = WORKLOADS[args.workload]
     cdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model, make_step, B, desc, wd = build_workload(args, w, dev, rank)
+    par = setup_parallel_groups(args, w, world, rank)          # None, or the Hybrid-OP / sequence-parallel groups of this rank
+    model, make_step, B, desc, wd = build_workload(args, w, dev, rank, par)
     model.set_compute_dtype(cdtype)
     net = model
     if world > 1:
         from UCF_VIT._hip.ddp import HipDataParallel
-        net = HipDataParallel(model)
+        # sequence parallelism: one MEAN over all dp x sp ranks (seq_parallel.GatherTokensFn carries the factor P); tensor parallelism:
+        # every rank owns its weight shards, only the data-parallel replicas of a lane reduce (reference: DDP over ddp_group)
+        net = HipDataParallel(model, process_group=par["ddp_group"] if par and par["tp"] > 1 else None)
     opt = configure_optimizer(model, 1e-4, 0.9, 0.95, wd)        # configs/*/base_config.yaml: lr, betas, wd
     sch = configure_scheduler(opt, 1000, 20000, 1e-8, 1e-8)
     step = make_step(net, opt, sch)
@@ -567,7 +633,8 @@ def main():
         mfma_stream = fl / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
     if rank == 0:
-        units = world * B * args.steps
+        dp = world // (args.sp * args.tp)                    # data-parallel replicas: a sequence- / tensor-parallel group works on ONE batch
+        units = dp * B * args.steps
         value = units / dt
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         fam = {}
@@ -584,18 +651,24 @@ def main():
             "conv": "conv3_fwd_kernel / conv3_wgrad_kernel (csrc/conv3d.hip): 3x3x3 implicit-GEMM convolutions on MFMA, channels-last bf16 — every "
                     "forward, data-gradient and weight-gradient launch of the timed region, algorithmic FLOPs 2 x 27 x voxels x Cin x Cout",
         }
-        step_tflops = value / world * train_flops_per_unit(w) / 1e12
+        step_tflops = value / world * train_flops_per_unit(w) / 1e12       # per GPU: the group's volumes spread over its ranks
         traffic, traffic_src = pmc_traffic(args.workload, args.dtype, B, dom)
         d = fam[dom]
         unit = "volumes/sec" if w["kind"] == "unetr" else "images/sec"
         headline = args.workload == "vit_l16_224" and args.dtype == "bf16"
+        parallelism = f"dp{dp}"
+        if args.sp > 1:
+            parallelism = (f"dp{dp} x " if dp > 1 else "") + f"sp{args.sp}{par['grid']}"      # (ring x Ulysses), e.g. sp8(2x4) for 12 heads on 8 GPUs
+        elif args.tp > 1:
+            parallelism = (f"dp{dp} x " if dp > 1 else "") + f"tp{args.tp}"
         res = {
             "metric": "images/sec/node ViT-L/16 224^2 bf16 train step" if headline else f"{unit.replace('/sec', '')}/sec/node {args.workload} {args.dtype} train step",
             "value": round(value, 3 if w["kind"] == "unetr" else 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} {desc}",
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+                       "per_gpu_batch": B, "global_batch": B * dp, "parallelism": parallelism, "final_loss": round(final_loss, 4),
+                       "per_group_batch_note": None if par is None else "per_gpu_batch is the batch of one sequence- / tensor-parallel group (its ranks share it)",
                        "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, " + ("RCCL" if backend == "nccl" else backend + " (rehearsal)") + ", overlapped with backward") if world > 1 else "none (1 rank)"},
             "roofline": {"bound": "mfma", "kernel": kernel_names[dom],
                          "achieved": round(d["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),

@@ -43,7 +43,19 @@ def test_parent_reports_a_failed_rank():
     if torch.cuda.is_available():
         pytest.skip("needs a box without a GPU")
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
-    assert r.returncode != 0 and "ranks failed" in r.stderr
+    assert r.returncode != 0 and "exited with code" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_parent_stops_the_other_ranks_when_one_dies():
+    """rank 1 exits before the rendezvous, rank 0 would wait for it in the process-group initialisation (30 minutes by default): the
+    parent polls every child, stops rank 0, names the failing (rank, exit code) and returns within seconds, without a JSON line"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0"], {"UCFVIT_BENCH_DRY": "1", "UCFVIT_BENCH_DRY_FAIL_RANK": "1"}, timeout=120)
+    dt = time.time() - t0
+    assert r.returncode != 0 and "rank 1 exited with code 3" in r.stderr, r.stderr[-1500:]
+    assert dt < 60, dt
     assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
 
 

@@ -45,6 +45,24 @@ def test_bench_gpus_2_self_launch_end_to_end():
     assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2" and "gloo" in d["config"]["grad_all_reduce"]
 
 
+def test_bench_config5_sequence_parallel_layout_self_launch():
+    """BASELINE config 5's layout from the command line: `--gpus 2 --sp 2` builds fsdp.arch.UNETR over init_par_groups' sequence-parallel
+    group (2-D Ulysses x ring view), HipDataParallel takes the mean over the dp x sp ranks; one group works on ONE batch, so the value
+    counts the group's volumes once.  (Rehearsal transport: both ranks on GPU 0, gloo.)"""
+    d = _bench(["--gpus", "2", "--sp", "2", "--steps", "2", "--warmup", "1", "--workload", "unetr_512x512x128", "--batch", "1", "--no-cpu-baseline"],
+               {"UCFVIT_BENCH_BACKEND": "gloo", "UCFVIT_BENCH_ONE_GPU": "1"}, timeout=1200)
+    _check(d, 2, "volumes/sec")
+    assert d["config"]["parallelism"] == "sp2(1x2)" and d["config"]["global_batch"] == 1
+    assert 0.3 < d["config"]["final_loss"] < 5.0
+
+
+def test_bench_config5_tensor_parallel_layout_self_launch():
+    d = _bench(["--gpus", "2", "--tp", "2", "--steps", "2", "--warmup", "1", "--workload", "unetr_enc_512x512x128", "--batch", "1", "--no-cpu-baseline"],
+               {"UCFVIT_BENCH_BACKEND": "gloo", "UCFVIT_BENCH_ONE_GPU": "1"}, timeout=1200)
+    _check(d, 2, "volumes/sec")
+    assert d["config"]["parallelism"] == "tp2" and d["config"]["global_batch"] == 1
+
+
 def test_bench_mae_workload_line():
     d = _bench(["--steps", "2", "--warmup", "1", "--workload", "mae_vit_l16_224", "--batch", "64", "--cpu-steps", "1"])
     _check(d, 1, "images/sec")

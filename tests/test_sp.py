@@ -191,8 +191,8 @@ def _unetr_sp_worker(rank, world, port, dtype_name, tol, ulysses, q):
                 bad.append("whole-model logits")
             for (k, p), (_, pr) in zip(m.named_parameters(), base.named_parameters()):
                 g = p.grad.detach().float().cpu()
-                if k.startswith(enc):
-                    dist.all_reduce(g)                           # encoder: sum of the shard contributions (decoder replicas count once)
+                dist.all_reduce(g)                               # the MEAN over the group (what HipDataParallel takes) is right for the
+                g /= world                                       # sharded encoder AND the replicated decoder: GatherTokensFn scales by P
                 rn = ((g - pr.grad.detach().float().cpu()).norm() / pr.grad.detach().float().norm().cpu().clamp_min(1e-20)).item()
                 if rn >= 0.25:                                   # bf16 decoder: gradient noise of tests/test_unetr_decoder_model.py
                     bad.append("whole-model grad " + k + f" {rn:.3f}")
@@ -232,3 +232,95 @@ def test_unetr_encoder_sequence_parallel_equals_unsharded(world, ulysses, dtype_
     for rank, bad, grid in res:
         assert grid == (ulysses, world // ulysses)
         assert not bad, f"SP rank {rank}: mismatch in {bad}"
+
+
+# ------------------------------------------------------------------------- the whole sequence-parallel UNETR under HipDataParallel
+def _unetr_sp_ddp_worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from UCF_VIT.fsdp.arch import UNETR
+        from UCF_VIT.fsdp.seq_parallel import make_seq_parallel_groups
+        from UCF_VIT.simple.arch import UNETR as UNETR1
+        from UCF_VIT._hip import functional as HF
+        from UCF_VIT._hip.ddp import HipDataParallel
+        from UCF_VIT.utils.misc import configure_optimizer
+        from det_weights import det_state_dict, det_tensor
+        img = [64, 64, 64]                                       # p 16 -> 64 tokens, 32 per rank
+        kw = dict(img_size=img, patch_size=16, in_chans=1, embed_dim=192, depth=2, num_heads=6, class_token=False, twoD=False, num_classes=4,
+                  linear_decoder=False, feature_size=16, skip_connection=True)
+        x = det_tensor((1, 1, *img), 82).to("cuda:0")
+        lab = (det_tensor((1, *img), 83) * 2).long().clamp_(0, 3).to("cuda:0")
+        base = UNETR1(**kw)
+        sd = det_state_dict(base, 81)
+        base.load_state_dict(sd)
+        base = base.to("cuda:0")
+        opt_b = configure_optimizer(base, 1e-3, 0.9, 0.95, 0.0)
+        HF.dice_ce(base(x, None), lab).backward()
+        g_ref = {k: p.grad.detach().float().cpu().clone() for k, p in base.named_parameters()}
+        opt_b.step()
+        w_ref = {k: p.detach().float().cpu().clone() for k, p in base.named_parameters()}
+        spg = make_seq_parallel_groups([list(range(world))], 6, ulysses_size=world)
+        m = UNETR(seq_par_size=world, seq_par_group=spg, **kw)
+        m.load_state_dict(sd)
+        m = m.to("cuda:0")
+        ddp = HipDataParallel(m, bucket_mb=0.25)                 # the documented reducer: a MEAN over the dp x sp ranks (here 1 x 2)
+        opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 0.0)
+        HF.dice_ce(ddp(x, None), lab).backward()
+        torch.cuda.synchronize()
+        bad = []
+        for k, p in m.named_parameters():
+            g = p.grad.detach().float().cpu()
+            rn = ((g - g_ref[k]).norm() / g_ref[k].norm().clamp_min(1e-20)).item()
+            if rn >= 0.25:                                       # bf16 decoder on both sides: the gradient noise of tests/test_unetr_decoder_model.py
+                bad.append(f"grad {k} {rn:.3f}")
+        # the scale is what the advisor's finding was about: a gradient 1/P of the right size would show as a norm ratio of 0.5
+        enc = [k for k in g_ref if k.startswith(("blocks.", "patch_embed.", "pos_embed"))]
+        ratio = sum(m.get_parameter(k).grad.float().norm().item() for k in enc) / sum(g_ref[k].norm().item() for k in enc)
+        if not 0.9 < ratio < 1.1:
+            bad.append(f"encoder gradient scale {ratio:.3f}")
+        opt.step()
+        for k, p in m.named_parameters():
+            d = (p.detach().float().cpu() - w_ref[k]).abs().max().item()
+            if d > 2.5e-3:                                       # Adam's first step moves every weight by ~lr = 1e-3 in the gradient's sign
+                bad.append(f"weight {k} {d:.2e}")
+        w = m._ucf_store.flat_p.detach().cpu()
+        w0 = w.clone()
+        dist.broadcast(w0, 0)
+        q.put((rank, bad, bool(torch.equal(w, w0))))
+        dist.barrier()
+    except Exception as e:
+        import traceback
+        q.put((rank, ["EXCEPTION " + repr(e) + " " + traceback.format_exc()[-1500:]], False))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_unetr_sequence_parallel_under_data_parallel_steps_like_the_unsharded_model():
+    """fsdp.arch.UNETR(seq_par_size=2) wrapped in HipDataParallel — the reducer DESIGN §7 prescribes — takes one optimiser step: every
+    gradient (encoder: sum of the shard contributions; decoder: replicated) and every post-step weight matches the unsharded model, and
+    both ranks end with identical weights (round-2 advisor finding: the encoder gradients came out 1 / P)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unetr_sp_ddp_worker, args=(r, world, 29611, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(world):
+        res.append(q.get(timeout=300))
+        if res[-1][1] and res[-1][1][0].startswith("EXCEPTION"):
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"rank {res[-1][0]}: {res[-1][1]}")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bad, same in res:
+        assert not bad, f"rank {rank}: {bad}"
+        assert same, "ranks diverged after the step"

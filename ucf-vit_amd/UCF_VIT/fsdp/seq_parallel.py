@@ -18,8 +18,11 @@ P = P_r x P_u (sp rank = r * P_u + u), chosen for the MI355X node — 8 GPUs ful
     all-to-all of the same bytes over seven, so P_u is taken as large as H allows: H = 12 on 8 ranks -> P_u = 4, P_r = 2.
 
 Parameter gradients are partial sums over the local tokens: reduce them over the sequence-parallel group together with the
-data-parallel reduction (HipDataParallel over the dp x sp group; with the local loss a MEAN over local tokens, the mean over ranks is
-the gradient of the global mean).  The pack / unpack permutes around the all-to-all are plain strided copies (torch) — data movement,
+data-parallel reduction — HipDataParallel over the dp x sp ranks, which takes a MEAN.  Two cases: (i) encoder only, every rank's loss
+a mean over its LOCAL tokens: the mean over ranks of the local gradients is the gradient of the global mean; (ii) the whole UNETR, whose
+loss every rank of the group computes identically behind gather_tokens_autograd: that function scales the gradient slices it hands
+back by P, so the same mean over ranks yields the SUM of the shard contributions for the encoder and leaves the replicated decoder's
+rank-identical gradients as they are (GatherTokensFn).  The pack / unpack permutes around the all-to-all are plain strided copies (torch) — data movement,
 no arithmetic; with B = 1 (the volume workload) the gathered side needs none: [P_u][1][N/P] IS the token order.
 """
 import math
@@ -319,7 +322,11 @@ def gather_tokens(x_local, spg):
 class GatherTokensFn(torch.autograd.Function):
     """differentiable gather_tokens for a consumer that every rank of the group runs IDENTICALLY on the gathered sequence (the UNETR
     convolutional decoder, replicated): forward all-gathers the shards, backward hands each rank the slice of the (rank-identical) gradient
-    that belongs to its shard — no reduction, the replicas count as one consumer"""
+    that belongs to its shard, SCALED BY THE GROUP SIZE.  The replicas count as one consumer, so the parameter gradients of the sharded
+    encoder are partial sums that need a SUM over the group while those of the replicated decoder are rank-identical and need a MEAN;
+    with the factor P in here one MEAN over the group — what HipDataParallel does over the dp x sp ranks — is right for both:
+    mean_r(P * partial_r) = sum_r partial_r for the encoder, mean_r(g) = g for the decoder (tests/test_sp.py:
+    test_unetr_sequence_parallel_under_data_parallel_steps_like_the_unsharded_model)."""
 
     @staticmethod
     def forward(ctx, x_local, spg):
@@ -330,7 +337,7 @@ class GatherTokensFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         lo = ctx.spg.rank * ctx.n
-        return g[:, lo:lo + ctx.n].contiguous(), None
+        return g[:, lo:lo + ctx.n] * float(ctx.spg.size), None
 
 
 def gather_tokens_autograd(x_local, spg):
