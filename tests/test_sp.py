@@ -250,7 +250,7 @@ def _unetr_sp_ddp_worker(rank, world, port, q):
         from UCF_VIT.utils.misc import configure_optimizer
         from det_weights import det_state_dict, det_tensor
         img = [64, 64, 64]                                       # p 16 -> 64 tokens, 32 per rank
-        kw = dict(img_size=img, patch_size=16, in_chans=1, embed_dim=192, depth=2, num_heads=6, class_token=False, twoD=False, num_classes=4,
+        kw = dict(img_size=img, patch_size=16, in_chans=1, embed_dim=192, depth=4, num_heads=6, class_token=False, twoD=False, num_classes=4,
                   linear_decoder=False, feature_size=16, skip_connection=True)
         x = det_tensor((1, 1, *img), 82).to("cuda:0")
         lab = (det_tensor((1, *img), 83) * 2).long().clamp_(0, 3).to("cuda:0")
