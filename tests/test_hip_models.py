@@ -174,7 +174,7 @@ def test_unetr_adaptive_sqrt_len_encoder_vs_oracle_and_trains():
     ref = R.SqrtLenVIT(kw["img_size"], patch_size=4, in_chans=1, num_classes=None, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False)
     sd = det_state_dict(ref, 71, keep=())
     ref.load_state_dict(sd)
-    m = UNETR(num_classes=3, linear_decoder=False, feature_size=4, skip_connection=True, adaptive_patching=True, fixed_length=8, sqrt_len=2,
+    m = UNETR(num_classes=3, linear_decoder=False, feature_size=4, skip_connection=True, allow_torch_decoder=True, adaptive_patching=True, fixed_length=8, sqrt_len=2,
               use_adaptive_pos_emb=True, sqrt_len_method=True, **kw)
     missing = m.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys
@@ -495,7 +495,7 @@ def test_unetr_encoder_3d_vs_oracle(dtype, tol):
     ref = R.VIT(kw["img_size"], patch_size=8, in_chans=1, num_classes=None, embed_dim=96, depth=4, num_heads=3, class_token=False, twoD=False)
     sd = det_state_dict(ref, 51)
     ref.load_state_dict(sd)
-    m = UNETR(num_classes=4, linear_decoder=False, feature_size=4, skip_connection=True, **kw)
+    m = UNETR(num_classes=4, linear_decoder=False, feature_size=4, skip_connection=True, allow_torch_decoder=True, **kw)
     missing = m.load_state_dict(sd, strict=False)
     assert all(k.split(".")[0] in ("encoder1", "encoder2", "encoder3", "encoder4", "decoder2", "decoder3", "decoder4", "decoder5", "out")
                for k in missing.missing_keys) and not missing.unexpected_keys
@@ -638,7 +638,7 @@ def test_train_sap_and_unetr_scripts_run_adaptive_configs(tmp_path):
     out = _run_entry("train_sap_simple.py", cfg, tmp_path, 29582)
     losses = [float(l.split("epoch_loss")[1].split()[0]) for l in out.splitlines() if "epoch_loss" in l]
     assert len(losses) == 2 and all(math.isfinite(v) for v in losses) and losses[1] < losses[0], out
-    a.update(tile_size=[32, 32, 32], patch_size=4, twoD=False, fixed_length=8, feature_size=4, depth=4)
+    a.update(tile_size=[32, 32, 32], patch_size=4, twoD=False, fixed_length=8, feature_size=4, depth=4, allow_torch_decoder=True)
     cfg["data"]["single_channel"] = True
     cfg["data"]["batch_size"] = 2
     cfg["load_balancing"]["batches_per_rank_epoch"]["catsdogs"] = 3
@@ -652,7 +652,7 @@ def test_train_unetr_simple_entry_point_runs(tmp_path):
     kernels + conv decoder, Dice+CE loss; 2 epochs on synthetic data"""
     cfg = _smoke_cfg()
     a = cfg["model"]["net"]["init_args"]
-    a.update(tile_size=[32, 32, 32], patch_size=8, embed_dim=96, depth=4, num_heads=3, twoD=False, feature_size=8)
+    a.update(tile_size=[32, 32, 32], patch_size=8, embed_dim=96, depth=4, num_heads=3, twoD=False, feature_size=8, allow_torch_decoder=True)
     cfg["data"]["num_classes"] = 3
     cfg["data"]["batch_size"] = 2
     cfg["data"]["single_channel"] = True
@@ -841,7 +841,7 @@ def test_mae_encoder_transfers_into_unetr_and_tp_checkpoint_names(tmp_path):
     mae = MAE(weight_init='skip', mask_ratio=0.75, linear_decoder=False, decoder_depth=1, decoder_embed_dim=48, decoder_num_heads=3,
               mlp_ratio_decoder=4.0, **enc)
     mae.load_state_dict(det_state_dict(mae, 91))
-    un = UNETR(num_classes=4, linear_decoder=False, feature_size=4, skip_connection=True, **enc)
+    un = UNETR(num_classes=4, linear_decoder=False, feature_size=4, skip_connection=True, allow_torch_decoder=True, **enc)
     before = {k: v.clone() for k, v in un.state_dict().items()}
     sd = {"module." + k: v for k, v in mae.state_dict().items()}             # a DDP-saved checkpoint
     copied = load_pretrained_mae_encoder(un, sd)

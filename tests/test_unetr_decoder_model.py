@@ -1,6 +1,6 @@
 """The whole UNETR (encoder + skip-connection convolutional decoder + Dice/CE loss) with the decoder on the HIP convolution kernels
 (UNETR.hip_decoder(), unetr_blocks.forward_cl) against the SAME model and weights with the decoder on torch/MIOpen fp32 convolutions
-(UCFVIT_UNETR_DECODER=torch).  Reference: src/UCF_VIT/simple/arch.py:757-1113, training_scripts/train_unetr_simple.py.  monai absent:
+(UNETR.force_torch_decoder, an explicit opt-in).  Reference: src/UCF_VIT/simple/arch.py:757-1113, training_scripts/train_unetr_simple.py.  monai absent:
 PARITY UNPINNED against it; the two paths share only the parameters and the ViT encoder.
 
 Tolerance of the gradients: through ~25 normalised layers at random initialisation the gradient is sensitive to WHERE values are rounded to
@@ -46,7 +46,8 @@ def _bf16_boundary_hooks(m):
 
 def _run(m, x, lab, decoder):
     from UCF_VIT._hip import functional as HF
-    os.environ["UCFVIT_UNETR_DECODER"] = decoder
+    m.allow_torch_decoder = True
+    m.force_torch_decoder = decoder == "torch"
     try:
         for p in m.parameters():
             p.grad = None
@@ -57,7 +58,7 @@ def _run(m, x, lab, decoder):
         flush_wgrads()
         return logits.detach().float().contiguous(), loss.item(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
     finally:
-        os.environ.pop("UCFVIT_UNETR_DECODER", None)
+        m.force_torch_decoder = False
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LayerNorm forward / backward kernel times at the ViT-L token matrix (env UCFVIT_LN_GRID_FWD / _BWD size the grids)."""
+"""LayerNorm forward / backward kernel times at the ViT-L token matrix (the grids are fixed in csrc/norm.hip: ln_grid_cap)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ucf-vit_amd"))

@@ -317,6 +317,8 @@ class SAP(VIT):
 
     def __init__(self, *args, **kwargs):
         self.sqrt_len = kwargs.pop('sqrt_len', '')
+        self.allow_torch_decoder = bool(kwargs.pop('allow_torch_decoder', False))
+        self.force_torch_decoder = False      # tests: the same weights through torch's convolutions (needs allow_torch_decoder)
         super().__init__(*args, **kwargs)
         self.head = None
         p = self.patch_size
@@ -433,8 +435,13 @@ class MAE(VIT):
 
 class UNETR(VIT):
     """UNETR (reference :757-1113): ViT encoder on the HIP kernels with taps after blocks depth/4, 2*depth/4, 3*depth/4
-    (raw block outputs, forward_intermediates :995-1086), conv decoder on torch/MIOpen (unetr_blocks.py, parity unpinned).
-    forward(x, variables, seq_ps=None, x_seq=None) -> [B, num_classes, *img_size]"""
+    (raw block outputs, forward_intermediates :995-1086) and the convolutional skip-connection decoder on the HIP convolution kernels
+    (csrc/conv3d.hip, csrc/unetr_decoder.hip through unetr_blocks.forward_cl; layer semantics = monai's published blocks, parity unpinned).
+    forward(x, variables, seq_ps=None, x_seq=None) -> [B, num_classes, *img_size]
+
+    ONE backend: a configuration the HIP decoder kernels do not cover (2-D, feature sizes other than 16 / 32 k, the pooling decoder
+    without skip connections, a patch size other than 16) raises in forward() unless the caller asked for torch's own convolutions
+    explicitly with the constructor argument allow_torch_decoder=True (an extension of the reference's signature; default False)."""
 
     def __init__(self, *args, **kwargs):
         self.linear_decoder = kwargs.pop('linear_decoder', '')
@@ -527,10 +534,9 @@ class UNETR(VIT):
         return self.unetr_head(self.pool(x), intermediates, enc1)
 
     def hip_decoder(self):
-        """True when the convolutional decoder runs on the HIP kernels end to end (unetr_blocks.hip_decoder_supported); UCFVIT_UNETR_DECODER=torch
-        forces the torch/MIOpen convolutions (the A/B of tests/test_unetr_decoder_model.py)"""
+        """True when the convolutional decoder runs on the HIP kernels end to end (unetr_blocks.hip_decoder_supported)"""
         from .unetr_blocks import hip_decoder_supported
-        if os.environ.get("UCFVIT_UNETR_DECODER", "hip") == "torch" or self.linear_decoder or not self.skip_connection:
+        if self.force_torch_decoder or self.linear_decoder or not self.skip_connection:
             return False
         full = all(self.feat_size[i] * 16 == self.img_size[i] for i in range(len(self.feat_size)))
         return full and hip_decoder_supported(2 if self.twoD else 3, self.in_chans, self.embed_dim, self.feature_size)
@@ -558,10 +564,20 @@ class UNETR(VIT):
                 enc1 = self.encoder1.forward_cl(_ops.pad_channels8(x.float().contiguous()))
                 feats, intermediates = self.forward_intermediates(tokens_in, variables, seq_ps, indices=self.skip_indices)
                 return self._unetr_head_cl(self.pool(feats), intermediates, enc1)
+            self._require_torch_decoder_opt_in()
             enc1 = self.encoder1(x)
             feats, intermediates = self.forward_intermediates(tokens_in, variables, seq_ps, indices=self.skip_indices)
             return self.forward_head(feats, intermediates, enc1)
+        if not self.linear_decoder:
+            self._require_torch_decoder_opt_in()
         return self.forward_head(self.forward_features(tokens_in, variables, seq_ps), None, None)
+
+    def _require_torch_decoder_opt_in(self):
+        if not self.allow_torch_decoder:
+            raise RuntimeError(
+                "UNETR: this configuration's convolutional decoder is not covered by the HIP convolution kernels (they need 3-D volumes, patch "
+                "size 16, the skip-connection decoder, feature_size 16 or a power-of-two multiple of 32, 1-8 input channels, an embed_dim of "
+                "8, 16 or a multiple of 32). Construct the model with allow_torch_decoder=True to run its convolutions on torch instead.")
 
 
 class DiffusionVIT(VIT):

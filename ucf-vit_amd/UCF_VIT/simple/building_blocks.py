@@ -258,7 +258,8 @@ class Block(nn.Module):
 
 class MyUnetBlock(nn.Module):
     """Transposed-conv upsampling stage of the skip-less UNETR decoder (reference :241-284; monai get_conv_layer(conv_only,
-    is_transposed) == a bias-free ConvTranspose).  Conv decoder arithmetic stays on MIOpen."""
+    is_transposed) == a bias-free ConvTranspose).  Not covered by the HIP convolution kernels: a model that uses it must be built with
+    UNETR(allow_torch_decoder=True) (torch's own convolutions; UNETR.forward raises otherwise)."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, upsample_kernel_size: int, res_block: bool = False) -> None:
         super().__init__()

@@ -9,8 +9,9 @@ Two execution paths over the SAME parameters (nn.Conv3d / nn.ConvTranspose3d mod
                    3x3x3 convolutions as implicit GEMMs on MFMA, transposed convolutions as GEMM + depth-to-space, instance norm + LeakyReLU
                    (+ residual) fused, csrc/conv3d.hip + csrc/unetr_decoder.hip through UCF_VIT/_hip/conv.py.  UNETR uses it whenever
                    hip_decoder_supported() holds (3-D, kernel 3 / stride 1 / upsample 2, channel counts the kernels tile).
-  forward(...)     N C (D) H W tensors: convolutions on torch/MIOpen with the fused HIP instance-norm kernels between them — the 2-D
-                   models and unusual channel counts.
+  forward(...)     N C (D) H W tensors: torch's own convolutions with the fused HIP instance-norm kernels between them — ONLY for models
+                   built with UNETR(allow_torch_decoder=True) (2-D, unusual channel counts); without that opt-in UNETR.forward raises
+                   instead of dropping to a second backend.
 """
 import torch
 import torch.nn as nn
@@ -129,7 +130,9 @@ class UnetOutBlock(nn.Module):
 def hip_decoder_supported(spatial_dims, in_chans, embed_dim, feature_size, kernel_size=3, upsample_kernel_size=2):
     """can the whole skip-connection decoder run on csrc/conv3d.hip?  3-D, 3x3x3 / 2x2x2 kernels, an input of <= 8 channels (zero-padded to the
     8-channel MFMA operand), feature_size a multiple of 16 whose multiples (x2, x4, x8, and the concatenations x2 .. x16) the kernels tile
-    (16, or any multiple of 32), embed_dim a multiple of 8"""
+    (16, or any multiple of 32), embed_dim one of the input widths the transposed-convolution / pointwise kernels tile (8, 16, or a
+    multiple of 32: _hip/conv.py conv3_cin_supported — 72 or 120 would pass a plain "% 8" rule and then fail inside forward)"""
     fs = feature_size
-    return (spatial_dims == 3 and kernel_size == 3 and upsample_kernel_size == 2 and 1 <= in_chans <= 8 and embed_dim % 8 == 0
+    return (spatial_dims == 3 and kernel_size == 3 and upsample_kernel_size == 2 and 1 <= in_chans <= 8
+            and (embed_dim in (8, 16) or (embed_dim > 0 and embed_dim % 32 == 0))
             and fs % 16 == 0 and (fs == 16 or fs % 32 == 0) and (fs & (fs - 1)) == 0)

@@ -24,14 +24,6 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
 int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
                                float scale, int dtype, hipStream_t s);
 
-static bool short_enabled() {
-    static int flag = -1;
-    if (flag < 0) {
-        const char* e = getenv("UCFVIT_ATTN_STREAM");
-        flag = (e && e[0] == '1') ? 0 : 1;
-    }
-    return flag == 1;
-}
 
 namespace {
 
@@ -773,8 +765,7 @@ template <typename T, int DH>
 int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int64_t B, int64_t N,
                     int64_t H, float scale, hipStream_t s) {
     // the FUSED backward (one launch, operands read once, delta taken from P and dP inside) is the default where it applies
-    static const bool fused_bwd = [] { const char* e = getenv("UCFVIT_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
-    if (short_enabled() && fused_bwd) {
+    {
         const int rc = ucfvit_attention_fused_bwd(qkv, dout, lse, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;
@@ -849,8 +840,9 @@ template <typename T, int DH>
 __global__ void attn_merge_kernel(float* __restrict__ o_acc, float* __restrict__ lse_acc, const T* __restrict__ o_part,
                                   const float* __restrict__ lse_part, int64_t B, int Nq, int H, int first) {
     constexpr int V = DH / 4;                                   // 4-element pieces per (token, head)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (b, q, h, piece)
-    if (i >= B * Nq * H * V) return;
+    const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, q, h, piece)
+    const bool valid = i_raw < B * Nq * H * V;                  // (a predicate, not an early return: every thread reaches the barrier below)
+    const int64_t i = valid ? i_raw : 0;
     const int piece = (int)(i % V);
     const int64_t bqh = i / V;
     const int h = (int)(bqh % H);
@@ -874,9 +866,9 @@ __global__ void attn_merge_kernel(float* __restrict__ o_acc, float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = o[e] * wa + p.get(e) * wp;
     }
-    *reinterpret_cast<f32x4*>(o_acc + i * 4) = r;
+    if (valid) *reinterpret_cast<f32x4*>(o_acc + i * 4) = r;
     __syncthreads();      // every piece of a (token, head) sits in one workgroup (V divides 256): all have read lse_acc before it changes
-    if (piece == 0) lse_acc[li] = ln;
+    if (valid && piece == 0) lse_acc[li] = ln;
 }
 
 template <typename T, int DH>
@@ -919,7 +911,7 @@ extern "C" int ucfvit_attention_fwd(const void* qkv, void* out, float* lse, int6
     int rc = check_attn_args("ucfvit_attention_fwd", B, N, H, dh, dtype);
     if (rc) return rc;
     UCF_CHECK_ARG(ucf_is_aligned16(qkv) && ucf_is_aligned16(out), "ucfvit_attention_fwd: pointers must be 16-byte aligned");
-    if (short_enabled()) {
+    {
         rc = ucfvit_attention_short_fwd(qkv, out, lse, B, N, H, dh, scale, dtype, (hipStream_t)stream);
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;

@@ -602,7 +602,6 @@ int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, void* 
     do {                                                 \
         if (nb <= 4) return FN<T, DH, 4>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;   \
         if (nb <= 8) return FN<T, DH, 8>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;   \
-        if (nb <= 13) return FN<T, DH, 13>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP; \
         return FN<T, DH, 16>(__VA_ARGS__) == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;               \
     } while (0)
 
@@ -611,8 +610,7 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
     // bf16 only: the fp32 instantiations exceed the register file (the exact-fp32 parity mode keeps the streaming kernels)
     if (dtype != UCFVIT_BF16 || N > 256 || (dh != 32 && dh != 64) || B * H >= (1ll << 31)) return 0;
     const int nb = (int)((N + 15) / 16);
-    static const bool s3 = [] { const char* e = getenv("UCFVIT_ATTN_FWD_S3"); return !(e && e[0] == '0'); }();
-    if (s3 && nb > 8 && nb <= 13) {
+    if (nb > 8 && nb <= 13) {          // 129 .. 208 tokens (N = 197): K and V resident as LDS images, three workgroups per CU
         const int rc = dh == 64 ? launch_s3_fwd<64, 13>(qkv, out, lse, B, N, H, scale, s) : launch_s3_fwd<32, 13>(qkv, out, lse, B, N, H, scale, s);
         return rc == UCFVIT_OK ? 1 : UCFVIT_ERR_HIP;
     }

@@ -756,12 +756,13 @@ int launch_fwd_mc(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, float* stat
     return UCFVIT_OK;
 }
 
-static int strip_mode() {          // UCFVIT_CONV_STRIP: 0 never, 1 (default) when the (x, y) columns fill the chip, 2 whenever the kernel applies (tests)
-    static int flag = -1;
-    if (flag < 0) {
+// UCFVIT_CONV_STRIP — a TEST hook (tests/test_conv3d.py runs every shape through both kernel families and compares them bit for bit):
+// 0 never, 1 (default) when the (x, y) columns fill the chip, 2 whenever the column kernel applies.  Read once (thread-safe static).
+static int strip_mode() {
+    static const int flag = [] {
         const char* e = getenv("UCFVIT_CONV_STRIP");
-        flag = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
-    }
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }();
     return flag;
 }
 

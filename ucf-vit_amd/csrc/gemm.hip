@@ -352,14 +352,6 @@ int dispatch_layout(const ucfvit_gemm_desc* d, const EpiArgs& ep, hipStream_t s)
 
 int ucfvit_gemm_v2_try(const ucfvit_gemm_desc* d, hipStream_t s);  // gemm2.hip
 
-static bool v2_enabled() {
-    static int flag = -1;
-    if (flag < 0) {
-        const char* e = getenv("UCFVIT_GEMM_V1");
-        flag = (e && e[0] == '1') ? 0 : 1;
-    }
-    return flag == 1;
-}
 
 extern "C" int ucfvit_gemm(const ucfvit_gemm_desc* d, void* stream) {
     UCF_CHECK_ARG(d != nullptr, "ucfvit_gemm: null descriptor");
@@ -376,7 +368,7 @@ extern "C" int ucfvit_gemm(const ucfvit_gemm_desc* d, void* stream) {
     UCF_CHECK_ARG(d->ldc >= d->N, "ucfvit_gemm: ldc too small");
     if (d->M == 0 || d->N == 0) return UCFVIT_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == UCFVIT_BF16 && v2_enabled()) {
+    if (d->dtype == UCFVIT_BF16) {
         const int rc = ucfvit_gemm_v2_try(d, s);   // large-tile DMA-pipelined kernel when the shape qualifies
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;

@@ -169,13 +169,10 @@ __device__ __forceinline__ void sched_leave(unsigned* sched, int tid) {
     }
 }
 
-__device__ int g_band_override = 0;      // experiments: UCFVIT_GEMM_BAND=n forces the band width (0 = the rule below)
-
 // logical tile index -> (m0, n0): bands of 8 N-tiles, walking down M inside a band (neighbouring tiles share operand panels)
 __device__ __forceinline__ void tile_origin(int t, int tiles_m, int tiles_n, int BM, int BN, int& m0, int& n0) {
     // 12 N-tiles (the qkv projection: N = 3072) as three bands of 4 rather than 8 + 4: every XCD block is 8 x 4 tiles
-    const int ov = g_band_override;
-    const int BAND = ov ? ov : ((tiles_n > 8 && tiles_n % 8 != 0 && tiles_n % 4 == 0) ? 4 : 8);
+    const int BAND = (tiles_n > 8 && tiles_n % 8 != 0 && tiles_n % 4 == 0) ? 4 : 8;
     const int band_tiles = BAND * tiles_m;
     const int band = t / band_tiles;
     const int band_w = min(BAND, tiles_n - band * BAND);
@@ -1019,22 +1016,12 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
     const int64_t ktiles_all = (d->K + BK2 - 1) / BK2;
     const bool plain_epi = !d->bias && !d->residual && !d->aux_in && !d->aux_out && d->act == UCFVIT_ACT_NONE;
     p->splits = 1;
-    static int force_small = -1;
-    if (force_small < 0) {
-        const char* e = getenv("UCFVIT_GEMM_SMALL");
-        force_small = (e && e[0] == '1') ? 1 : 0;
-    }
-    if (t256 >= 192 && !force_small) {
+    if (t256 >= 192) {
         p->big = 1;
     } else {
         p->big = 0;
         if (plain_epi && t128 < 384) {
-            static int target = 0;
-            if (!target) {
-                const char* e = getenv("UCFVIT_GEMM_SPLIT_TARGET");
-                target = e ? atoi(e) : 384;
-                if (target < 8) target = 384;
-            }
+            constexpr int target = 384;
             // split-K so that every XCD owns whole 8 x 8-tile blocks (64 resident workgroups = 2 per CU) of ONE K-slice and
             // all 8 XCDs are busy in every round: nb64 * s block-slices must be a multiple of 8 (see Sched2)
             const int64_t tm = (d->M + 127) / 128, tn = (d->N + 127) / 128;
@@ -1046,12 +1033,6 @@ inline bool plan2(const ucfvit_gemm_desc* d, Plan2* p) {
             const int kmax = (int)(ktiles_all / 8);          // at least 8 K-tiles per slice
             if (s > kmax) s = kmax;
             if (s < 1) s = 1;
-            static int force_splits = -1;
-            if (force_splits < 0) {
-                const char* e = getenv("UCFVIT_GEMM_SPLITS");   // experiments only
-                force_splits = e ? atoi(e) : 0;
-            }
-            if (force_splits > 0) s = force_splits < kmax ? force_splits : (kmax > 0 ? kmax : 1);
             p->splits = s;
         }
     }
@@ -1139,21 +1120,11 @@ int launch3g(const GroupsT<NP>& gt, int K, const Epi2& ep, int splits, int k_per
     // persistent grid = the CUs this launch may count on.  One 512-thread workgroup fills a CU's register file, so a CU that hosts a
     // wave of another kernel (an RCCL all-reduce overlapping backward) cannot take one: a grid larger than the free CUs leaves
     // workgroups waiting for a whole tile list.  UCFVIT_GEMM_CUS (default 256) lets a multi-GPU job reserve the CUs RCCL uses.
-    static bool band_done = false;
-    if (!band_done) {
-        band_done = true;
-        const char* eb = getenv("UCFVIT_GEMM_BAND");
-        if (eb) {
-            int v = atoi(eb);
-            if (v >= 1 && v <= 64) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_band_override), &v, sizeof(int));
-        }
-    }
-    static int cus = 0;
-    if (!cus) {
+    static const int cus = [] {                 // read once (thread-safe static: forward and autograd threads both launch GEMMs)
         const char* e = getenv("UCFVIT_GEMM_CUS");
-        cus = e ? atoi(e) : 256;
-        if (cus < 8 || cus > 256) cus = 256;
-    }
+        const int v = e ? atoi(e) : 256;
+        return (v < 8 || v > 256) ? 256 : v;
+    }();
     int cap = cus / splits;
     if (cap < 1) cap = 1;
     const int gx = gt.total_tiles < cap ? gt.total_tiles : cap;
@@ -1213,23 +1184,8 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
     return launch3g<LA, LB, OutT, EPI_GENERIC, false, 1>(gt, (int)d->K, ep, p.splits, p.k_per_split, s);
 }
 
-static bool generic_epilogue_only() {
-    static int flag = -1;
-    if (flag < 0) {
-        const char* e = getenv("UCFVIT_GEMM_GENERIC_EPI");   // experiments / A-B runs
-        flag = (e && e[0] == '1') ? 1 : 0;
-    }
-    return flag == 1;
-}
-
-static bool pp_enabled() {
-    static int flag = -1;
-    if (flag < 0) {
-        const char* e = getenv("UCFVIT_GEMM_NOPP");
-        flag = (e && e[0] == '1') ? 0 : 1;
-    }
-    return flag == 1;
-}
+static bool generic_epilogue_only() { return false; }
+static bool pp_enabled() { return true; }
 
 template <int LA, int LB, typename OutT>
 int dispatch_tile(const ucfvit_gemm_desc* d, const Plan2& p, const Epi2& ep, hipStream_t s) {

@@ -559,12 +559,14 @@ template <int EPI, bool CS, int E> int s5_launch(const StaggerArgs& a, hipStream
     return UCFVIT_OK;
 }
 
+// UCFVIT_GEMM_STAGGER — a TEST / measurement hook: 0 keeps every launch on gemm3_kernel (tests/test_hip_ops.py compares the dynamic tile
+// schedule with the static order of the SAME kernel; tools/block_gemm_bench.py A/B), 1 / 2 / 4 / 8 force the number of epilogue steps
+// (tests/test_gemm_stagger.py runs every variant).  Read once (thread-safe static).
 int s5_steps_override() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("UCFVIT_GEMM_STAGGER");      // development A/B switch: 0 = off, 1 / 2 / 4 / 8 = epilogue steps
-        v = e ? atoi(e) : -1;
-    }
+    static const int v = [] {
+        const char* e = getenv("UCFVIT_GEMM_STAGGER");
+        return e ? atoi(e) : -1;
+    }();
     return v;
 }
 

@@ -254,18 +254,7 @@ inline int colsum_chunks(int64_t M) {
 // workgroups of 4 waves (one row per wave at a time).  Forward: 2048 workgroups = 32 waves per CU (bytes in flight = resident
 // waves x one row; +0.9 % on the ViT-L step over 512).  Backward: 768 = the three workgroups per CU its registers allow (61 us at
 // 512, 54 us at 768, 68 us at 832 where a second partial round starts; tools/ln_bench.py).
-inline int ln_grid_cap(bool backward) {
-    static int fwd = 0, bwd = 0;
-    if (!fwd) {
-        const char* e = getenv("UCFVIT_LN_GRID_FWD");
-        const char* b = getenv("UCFVIT_LN_GRID_BWD");
-        fwd = e ? atoi(e) : 2048;
-        bwd = b ? atoi(b) : 768;
-        if (fwd < 1) fwd = 2048;
-        if (bwd < 1) bwd = 768;
-    }
-    return backward ? bwd : fwd;
-}
+inline int ln_grid_cap(bool backward) { return backward ? 768 : 2048; }
 inline int ln_grid(int64_t rows, bool backward = true) {
     int64_t g = (rows + 3) / 4;
     const int cap = ln_grid_cap(backward);

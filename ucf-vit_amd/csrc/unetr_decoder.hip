@@ -1,7 +1,8 @@
 // HBM-bound kernels of the UNETR convolutional decoder for gfx950: the normalisation / activation / residual chain of
 // the residual conv blocks and the Dice + cross-entropy loss, each as ONE read of its inputs per pass instead of torch's chain of
-// element-wise kernels.  (The 3x3x3 / transposed convolutions themselves stay on MIOpen; these kernels take and return torch's N C (D) H W
-// layout: a (batch, channel) pair is one contiguous row of S voxels.)
+// element-wise kernels.  Two families: the channels-last kernels (incl_*) that sit between the HIP convolution kernels of csrc/conv3d.hip —
+// the product path of the 3-D skip-connection decoder — and the N C (D) H W row kernels (a (batch, channel) pair is one contiguous row of
+// S voxels) for models whose convolutions the caller opted to run on torch (UNETR(allow_torch_decoder=True): 2-D, other channel counts).
 //
 //   reference call sites: src/UCF_VIT/simple/arch.py:808-940 (monai UnetrBasicBlock / UnetrPrUpBlock / UnetrUpBlock: UnetResBlock =
 //   conv -> instance norm -> LeakyReLU(0.01) -> conv -> instance norm, + (1x1 conv -> instance norm | identity), LeakyReLU),

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """UNETR segmentation training — entry point compatible with the reference's training_scripts/train_unetr_simple.py.
-The ViT encoder runs on the HIP kernels, and so do the decoder's instance-norm / LeakyReLU / residual chains and the Dice+CE loss (monai
-DiceCELoss(to_onehot_y, softmax, squared_pred) in the reference, :38; parity unpinned: monai is not vendored); its convolutions are MIOpen's."""
+The ViT encoder, the convolutional decoder (3x3x3 / transposed / 1x1x1 convolutions on csrc/conv3d.hip, channels-last instance-norm /
+LeakyReLU / residual chains on csrc/unetr_decoder.hip) and the Dice+CE loss (monai DiceCELoss(to_onehot_y, softmax, squared_pred) in the
+reference, :38; parity unpinned: monai is not vendored) all run on the HIP kernels.  A configuration those kernels do not cover (2-D,
+feature sizes other than 16 / 32 k, ...) needs `allow_torch_decoder: True` in model.net.init_args, else UNETR.forward raises."""
 import sys
 
 import torch
@@ -41,6 +43,7 @@ def main(device, local_rank, rank, world):
     m = conf["model"]
     model = UNETR(num_classes=d["num_classes"], class_token=False, weight_init='', linear_decoder=a.get("linear_decoder", False),
                   feature_size=a.get("feature_size", 16), skip_connection=a.get("skip_connection", True), sqrt_len=sqrt_len,
+                  allow_torch_decoder=bool(a.get("allow_torch_decoder", False)),   # explicit opt-in for configurations the HIP decoder does not cover
                   sqrt_len_method=adaptive, FusedAttn_option=FusedAttn.HIP, **margs).to(device)
     model.set_compute_dtype(torch.bfloat16 if conf["trainer"].get("data_type", "float32") == "bfloat16" else torch.float32)
     net = HipDataParallel(model)
