@@ -317,8 +317,6 @@ class SAP(VIT):
 
     def __init__(self, *args, **kwargs):
         self.sqrt_len = kwargs.pop('sqrt_len', '')
-        self.allow_torch_decoder = bool(kwargs.pop('allow_torch_decoder', False))
-        self.force_torch_decoder = False      # tests: the same weights through torch's convolutions (needs allow_torch_decoder)
         super().__init__(*args, **kwargs)
         self.head = None
         p = self.patch_size
@@ -448,6 +446,8 @@ class UNETR(VIT):
         self.feature_size = kwargs.pop('feature_size', '')
         self.skip_connection = kwargs.pop('skip_connection', '')
         self.sqrt_len = kwargs.pop('sqrt_len', '')
+        self.allow_torch_decoder = bool(kwargs.pop('allow_torch_decoder', False))
+        self.force_torch_decoder = False      # tests: the same weights through torch's convolutions (needs allow_torch_decoder)
         super().__init__(*args, **kwargs)
         self.head = None
         from .unetr_blocks import UnetrBasicBlock, UnetrPrUpBlock, UnetrUpBlock, UnetOutBlock
