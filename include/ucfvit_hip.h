@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 8
+#define UCFVIT_ABI_VERSION 9
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -346,6 +346,19 @@ int ucfvit_dice_ce_strided(const void* logits, const int64_t* labels, float* los
                            int64_t stride_b, int64_t stride_c, int64_t stride_s, float smooth_nr, float smooth_dr, float grad_scale,
                            void* workspace, int dtype, void* stream);
 
+/* Dice + CE over a volume SHARDED across the ranks of a sequence-parallel group (X-slabs of the UNETR decoder; no reference counterpart: the
+ * reference asserts seq_par_size == 1, training_scripts/train_masked_fsdp.py:220 — the loss itself is train_unetr_simple.py:38).  Every term
+ * is a function of per-(batch, class) sums over voxels: ucfvit_dice_ce_stats writes this rank's sums (stats: B x ucfvit_dice_ce_stats_floats()
+ * floats; workspace: ucfvit_dice_ce_workspace bytes), the caller adds them over the group, ucfvit_dice_ce_from_stats evaluates the loss of the
+ * WHOLE volume from the summed stats (rewritten in place) and the gradient of the LOCAL logits (S local voxels, S_total voxels of the whole
+ * volume, both per batch element).  Unsharded: S_total = S and the pair equals ucfvit_dice_ce_strided. */
+int ucfvit_dice_ce_stats_floats(void);
+int ucfvit_dice_ce_stats(const void* logits, const int64_t* labels, float* stats, int64_t B, int64_t n, int64_t S, int64_t stride_b, int64_t stride_c,
+                         int64_t stride_s, void* workspace, int dtype, void* stream);
+int ucfvit_dice_ce_from_stats(const void* logits, const int64_t* labels, float* stats, float* loss, void* dlogits, int64_t B, int64_t n, int64_t S,
+                              int64_t S_total, int64_t stride_b, int64_t stride_c, int64_t stride_s, float smooth_nr, float smooth_dr,
+                              float grad_scale, int dtype, void* stream);
+
 /* Channels-last instance norm (+ LeakyReLU, + residual) for the layout of the convolution kernels below: x, res, y [B][S][C] bf16,
  * mean / rstd [B][C] fp32; C a power of two in 8..2048.  Same formulas as ucfvit_instnorm_fwd / _bwd.  had_res: the forward pass added a
  * residual, so the activation mask is read from y; without one sign(y) = sign(x - mean) and y is not read at all (dres requires had_res).
@@ -355,6 +368,15 @@ int ucfvit_instnorm_cl_fwd(const void* x, const void* res, void* y, float* mean,
                            float slope, void* workspace, void* stream);
 int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, void* dx, void* dres, int64_t B,
                            int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* workspace, void* stream);
+
+/* ucfvit_instnorm_cl_bwd in two calls, for a volume sharded across ranks: _bwd_sums leaves the per-(batch, channel) MEANS over the local voxels
+ * of dy' (the gradient behind the activation mask) and of dy' xhat in m1 / m2 [B][C]; the caller averages them over the ranks (equal slabs:
+ * the mean over the whole volume) and passes them to _bwd_apply.  (The forward statistics of a sharded volume combine the same way from
+ * ucfvit_instnorm_cl_stats: mean = avg(mean_r), var = avg(var_r + mean_r^2) - mean^2.) */
+int ucfvit_instnorm_cl_bwd_sums(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, float* m1, float* m2, int64_t B,
+                                int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* workspace, void* stream);
+int ucfvit_instnorm_cl_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* m1, const float* m2,
+                                 void* dx, void* dres, int64_t B, int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* stream);
 
 /* The tail of a residual block whose residual branch is itself normalised (monai UnetResBlock with the 1x1x1 projection):
  *   ucfvit_instnorm_cl_stats:  mean / rstd of x only (ucfvit_instnorm_cl_fwd = this + the apply pass)

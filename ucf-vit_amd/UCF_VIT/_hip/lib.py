@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
 GEMM_SCHED_BYTES = 1024
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
@@ -77,6 +77,11 @@ SIGNATURES = {
     "ucfvit_dice_ce_workspace": (_I64, [_I64, _I64]),
     "ucfvit_dice_ce": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _P, _I, _P]),
     "ucfvit_dice_ce_strided": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _F, _F, _P, _I, _P]),
+    "ucfvit_dice_ce_stats_floats": (c_int, []),
+    "ucfvit_dice_ce_stats": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I, _P]),
+    "ucfvit_dice_ce_from_stats": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _F, _F, _I, _P]),
+    "ucfvit_instnorm_cl_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P, _P]),
+    "ucfvit_instnorm_cl_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_instnorm_cl_workspace": (_I64, [_I64, _I64, _I64]),
     "ucfvit_instnorm_cl_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _P, _P]),
     "ucfvit_instnorm_cl_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P, _P]),

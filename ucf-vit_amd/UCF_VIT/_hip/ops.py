@@ -597,6 +597,64 @@ def dice_ce(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5, grad_scale=1.0, want
     return loss, dl
 
 
+def _dice_strides(logits, B, n, S):
+    """(stride_b, stride_c, stride_s) of contiguous N C (D) H W logits or of a channels-last view with contiguous voxel rows"""
+    if logits.is_contiguous():
+        return n * S, S, 1
+    cl = logits.movedim(1, -1)                           # [B, *spatial, n]
+    ld = cl.stride(-2)
+    ok = cl.stride(-1) == 1 and ld >= n and cl.stride(0) == S * ld
+    exp = ld
+    for d in range(cl.dim() - 2, 0, -1):
+        ok = ok and cl.stride(d) == exp
+        exp *= cl.shape[d]
+    if not ok:
+        raise RuntimeError("dice_ce: logits must be contiguous or a channels-last view with contiguous voxel rows")
+    return S * ld, 1, ld
+
+
+def dice_ce_stats(logits, labels):
+    """this rank's per-(batch, class) sums of the Dice + CE loss over its slab of a sharded volume: fp32 [B, ucfvit_dice_ce_stats_floats()]
+    (to be summed over the group and handed to dice_ce_from_stats)"""
+    L = _l.load()
+    _chk(labels, "dice_ce_stats.labels")
+    if not logits.is_cuda:
+        _chk(logits, "dice_ce_stats.logits")
+    if labels.dtype != torch.int64:
+        raise TypeError("dice_ce_stats: labels must be int64")
+    B, n = logits.shape[0], logits.shape[1]
+    S = logits.numel() // (B * n)
+    if labels.numel() != B * S:
+        raise ValueError("dice_ce_stats: labels must hold one class index per local voxel")
+    sb, sc, ss = _dice_strides(logits, B, n, S)
+    stats = torch.empty((B, L.ucfvit_dice_ce_stats_floats()), dtype=torch.float32, device=logits.device)
+    ws = workspace(L.ucfvit_dice_ce_workspace(B, S), logits.device)
+    _l.check(L.ucfvit_dice_ce_stats(logits.data_ptr(), labels.data_ptr(), stats.data_ptr(), B, n, S, sb, sc, ss, ws.data_ptr(), dt(logits), _stream()),
+             "ucfvit_dice_ce_stats")
+    return stats
+
+
+def dice_ce_from_stats(logits, labels, stats, S_total, smooth_nr=1e-5, smooth_dr=1e-5, grad_scale=1.0, want_grad=True):
+    """stats: the per-(batch, class) sums of the WHOLE volume (dice_ce_stats summed over the group) -> (loss of the whole volume, gradient of the
+    LOCAL logits or None).  S_total: voxels of the whole volume per batch element."""
+    L = _l.load()
+    B, n = logits.shape[0], logits.shape[1]
+    S = logits.numel() // (B * n)
+    sb, sc, ss = _dice_strides(logits, B, n, S)
+    if want_grad:
+        if logits.is_contiguous():
+            dl = torch.empty_like(logits)
+        else:
+            dl = torch.zeros(B * sb, dtype=logits.dtype, device=logits.device).as_strided(logits.shape, logits.stride())
+    else:
+        dl = None
+    stats = stats.clone()                                # rewritten in place by the fold
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    _l.check(L.ucfvit_dice_ce_from_stats(logits.data_ptr(), labels.data_ptr(), stats.data_ptr(), loss.data_ptr(), _p(dl), B, n, S, int(S_total), sb, sc, ss,
+                                         smooth_nr, smooth_dr, grad_scale, dt(logits), _stream()), "ucfvit_dice_ce_from_stats")
+    return loss, dl
+
+
 # ------------------------------------------------------------------------------------------------ UNETR decoder, channels-last bf16
 def _chk_cl(t, name, C=None):
     _chk(t, name)
@@ -837,6 +895,39 @@ def instnorm_cl_bwd(dy, y, x, mean, rstd, slope, want_dres, had_res=None):
     had_res = want_dres if had_res is None else had_res
     _l.check(L.ucfvit_instnorm_cl_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), B, S, C,
                                       ld, slope, 1 if had_res else 0, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd")
+    return dx, dres
+
+
+def instnorm_cl_bwd_sums(dy, y, x, mean, rstd, slope, had_res):
+    """first half of instnorm_cl_bwd for a sharded volume: (m1, m2) [B, C] = the means over the LOCAL voxels of dy' and dy' xhat"""
+    L = _l.load()
+    _chk_cl(x, "instnorm_cl_bwd_sums.x")
+    ld = cl_row_stride(dy)
+    if ld is None or dy.shape != x.shape:
+        dy = _chk_cl(dy.contiguous(), "instnorm_cl_bwd_sums.dy")
+        ld = dy.shape[-1]
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    m1 = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    m2 = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ws = workspace(L.ucfvit_instnorm_cl_workspace(B, S, C), x.device)
+    _l.check(L.ucfvit_instnorm_cl_bwd_sums(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                           B, S, C, ld, slope, 1 if had_res else 0, ws.data_ptr(), _stream()), "ucfvit_instnorm_cl_bwd_sums")
+    return m1, m2, dy
+
+
+def instnorm_cl_bwd_apply(dy, y, x, mean, rstd, m1, m2, slope, want_dres, had_res):
+    L = _l.load()
+    ld = cl_row_stride(dy)
+    if ld is None or dy.shape != x.shape:
+        dy = _chk_cl(dy.contiguous(), "instnorm_cl_bwd_apply.dy")
+        ld = dy.shape[-1]
+    B, C = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    _l.check(L.ucfvit_instnorm_cl_bwd_apply(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                            dx.data_ptr(), _p(dres), B, S, C, ld, slope, 1 if had_res else 0, _stream()), "ucfvit_instnorm_cl_bwd_apply")
     return dx, dres
 
 

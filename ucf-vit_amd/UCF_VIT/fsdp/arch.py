@@ -101,11 +101,17 @@ class UNETR(_TPMixin, _S.UNETR):
                         process group (pure Ulysses, num_heads % seq_par_size == 0)
 
     With seq_par_size > 1 every rank embeds and encodes its contiguous shard of the token sequence: forward_intermediates returns the
-    LOCAL shards [B, N / P, D] of the final features and of the taps (seq_parallel.gather_tokens reassembles them for the decoder)."""
+    LOCAL shards [B, N / P, D] of the final features and of the taps.  The convolutional decoder then runs SHARDED as well
+    (shard_decoder=True, the default whenever the HIP decoder applies and the token grid's first axis divides by P): a token shard is an
+    X-slab of the token grid, every rank decodes its slab of the volume with one-plane halo exchanges in front of the 3x3x3 layers and
+    group-wide instance-norm statistics (fsdp/sharded_decoder.py), and forward() returns the LOCAL slab of the logits
+    [B, classes, X / P, Y, Z] — pair it with sharded_decoder.sharded_dice_ce and sharded_decoder.local_slab(labels, ...).
+    shard_decoder=False keeps the round-2 form: the shards are all-gathered and the decoder runs replicated on every rank."""
 
     def __init__(self, *args, **kwargs):
         self.seq_par_size = kwargs.pop('seq_par_size', 1)
         seq_par_group = kwargs.pop('seq_par_group', None)
+        self._shard_decoder_arg = kwargs.pop('shard_decoder', None)
         kwargs = self._tp_setup(kwargs)
         super().__init__(*args, **kwargs)
         object.__setattr__(self, '_spg', None)
@@ -173,6 +179,8 @@ class UNETR(_TPMixin, _S.UNETR):
         if self.seq_par_size <= 1:
             return super().forward(x, variables, seq_ps, x_seq)
         assert self.skip_connection and not self.linear_decoder, "sequence parallelism is wired for the skip-connection decoder"
+        if self.shard_decoder():
+            return self._forward_sharded_decoder(x, variables, seq_ps)
         from .seq_parallel import gather_tokens_autograd
         feats, taps = self.forward_intermediates(x, variables, seq_ps, indices=self.skip_indices)
         feats = gather_tokens_autograd(feats, self._spg)
@@ -182,6 +190,38 @@ class UNETR(_TPMixin, _S.UNETR):
             enc1 = self.encoder1.forward_cl(_ops.pad_channels8(x.float().contiguous()))
             return self._unetr_head_cl(self.pool(feats), taps, enc1)
         return self.forward_head(feats, taps, self.encoder1(x))
+
+
+    # -------------------------------------------------------------------------------------------- sharded decoder (fsdp/sharded_decoder.py)
+    def shard_decoder(self):
+        """True when forward() decodes only this rank's X-slab (see the class docstring)"""
+        if self.seq_par_size <= 1:
+            return False
+        can = self.hip_decoder() and len(self.feat_size) == 3 and self.feat_size[0] % self.seq_par_size == 0
+        if self._shard_decoder_arg is None:
+            return can
+        if self._shard_decoder_arg and not can:
+            raise ValueError("UNETR: shard_decoder=True needs the HIP decoder and a token grid whose first axis divides by seq_par_size")
+        return bool(self._shard_decoder_arg)
+
+    def _tokens_cl_local(self, t):
+        fx, fy, fz = self.feat_size
+        return t.to(torch.bfloat16).reshape(t.size(0), fx // self.seq_par_size, fy, fz, self.embed_dim)
+
+    def _forward_sharded_decoder(self, x, variables, seq_ps):
+        from . import sharded_decoder as SD
+        from UCF_VIT._hip import ops as _ops
+        spg = self._spg
+        feats, taps = self.forward_intermediates(x, variables, seq_ps, indices=self.skip_indices)       # local token shards = X-slabs
+        xl = SD.local_slab(x, spg, 2).float().contiguous()                                              # [B, C, X / P, Y, Z]
+        enc1 = SD.sharded_basic_block(self.encoder1, _ops.pad_channels8(xl), spg)
+        tok = self._tokens_cl_local
+        n = len(taps)
+        dec3 = SD.sharded_up_block(self.decoder5, tok(self.pool(feats)), SD.sharded_prup_block(self.encoder4, tok(taps[n - 1]), spg), spg)
+        dec2 = SD.sharded_up_block(self.decoder4, dec3, SD.sharded_prup_block(self.encoder3, tok(taps[n - 2]), spg), spg)
+        dec1 = SD.sharded_up_block(self.decoder3, dec2, SD.sharded_prup_block(self.encoder2, tok(taps[n - 3]), spg), spg)
+        logits = self.out.forward_cl(SD.sharded_up_block(self.decoder2, dec1, enc1, spg))                # [B, X / P, Y, Z, classes] fp32
+        return logits.permute(0, 4, 1, 2, 3)
 
 
 class SAP(_TPMixin, _S.SAP):

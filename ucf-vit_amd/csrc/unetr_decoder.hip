@@ -253,13 +253,13 @@ __global__ __launch_bounds__(64) void dice_final(const float* __restrict__ part,
 template <typename T>
 __global__ __launch_bounds__(NT) void dice_bwd(const T* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ stats,
                                                T* __restrict__ dlogits, int B, int n, int64_t S, float s_nr, float s_dr, float gscale,
-                                               int64_t sb, int64_t sc, int64_t ss) {
+                                               int64_t sb, int64_t sc, int64_t ss, int64_t S_total) {
     const int64_t b = blockIdx.y;
     const T* lb = logits + b * sb;
     T* db = dlogits + b * sb;
     const int64_t* yb = labels + b * S;
     float a[MAXC], bq[MAXC];                   // g_c = a_c onehot_c + bq_c p_c
-    const float wb = 1.f / ((float)B * (float)n), wce = 1.f / ((float)B * (float)S);
+    const float wb = 1.f / ((float)B * (float)n), wce = 1.f / ((float)B * (float)S_total);      // S_total: voxels of the WHOLE volume (= S unless sharded)
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const float I = stats[b * DSTAT + c], D = stats[b * DSTAT + MAXC + c] + stats[b * DSTAT + 2 * MAXC + c] + s_dr;
@@ -756,10 +756,53 @@ extern "C" int ucfvit_dice_ce_strided(const void* logits, const int64_t* labels,
         if (dlogits) {
             const dim3 g(apply_grid(S * 4, B), (unsigned)B);
             hipLaunchKernelGGL((dice_bwd<T>), g, dim3(NT), 0, s, (const T*)logits, labels, stats, (T*)dlogits, (int)B, (int)n, S, smooth_nr,
-                               smooth_dr, grad_scale, stride_b, stride_c, stride_s);
+                               smooth_dr, grad_scale, stride_b, stride_c, stride_s, S);
         }
     });
     UCF_LAUNCH_CHECK("ucfvit_dice_ce");
+    return UCFVIT_OK;
+}
+
+// The same loss over a volume that is SHARDED across the ranks of a sequence-parallel group (X-slabs of the decoder, fsdp/sharded_decoder.py):
+// every term of it is a function of per-(batch, class) SUMS over voxels, so a rank takes the sums of its slab (ucfvit_dice_ce_stats), the
+// caller adds them over the group (one all-reduce of B x 25 floats), and ucfvit_dice_ce_from_stats turns the global sums into the loss
+// value and into the gradient of the local logits (S_total = voxels of the whole volume per batch element).
+extern "C" int ucfvit_dice_ce_stats(const void* logits, const int64_t* labels, float* stats, int64_t B, int64_t n, int64_t S, int64_t stride_b,
+                                    int64_t stride_c, int64_t stride_s, void* workspace, int dtype, void* stream) {
+    UCF_CHECK_ARG(logits && labels && stats && workspace, "ucfvit_dice_ce_stats: null pointer");
+    UCF_CHECK_ARG(B > 0 && B < 65536 && S > 0 && n >= 2 && n <= MAXC, "ucfvit_dice_ce_stats: need 2 <= classes <= %d, B in 1..65535", MAXC);
+    UCF_CHECK_ARG(dtype == UCFVIT_F32 || dtype == UCFVIT_BF16, "ucfvit_dice_ce_stats: bad dtype %d", dtype);
+    UCF_CHECK_ARG(stride_b > 0 && stride_c > 0 && stride_s > 0, "ucfvit_dice_ce_stats: strides must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = chunks_of(S);
+    float* part = (float*)workspace;
+    float* scratch_loss = part + B * ch * DSTAT;          // (the local loss value is of no use: the first word of the stats area of the workspace)
+    IN_DISPATCH(T, {
+        hipLaunchKernelGGL((dice_partial<T>), dim3(ch, (unsigned)B), dim3(NT), 0, s, (const T*)logits, labels, part, (int)n, S, ch, stride_b,
+                           stride_c, stride_s);
+    });
+    hipLaunchKernelGGL(dice_final, dim3(1), dim3(64), 0, s, part, stats, scratch_loss, (int)B, (int)n, S, ch, 1.0f, 1.0f);
+    UCF_LAUNCH_CHECK("ucfvit_dice_ce_stats");
+    return UCFVIT_OK;
+}
+extern "C" int ucfvit_dice_ce_stats_floats(void) { return DSTAT; }
+extern "C" int ucfvit_dice_ce_from_stats(const void* logits, const int64_t* labels, float* stats, float* loss, void* dlogits, int64_t B, int64_t n,
+                                         int64_t S, int64_t S_total, int64_t stride_b, int64_t stride_c, int64_t stride_s, float smooth_nr,
+                                         float smooth_dr, float grad_scale, int dtype, void* stream) {
+    UCF_CHECK_ARG(logits && labels && stats && loss, "ucfvit_dice_ce_from_stats: null pointer");
+    UCF_CHECK_ARG(B > 0 && B < 65536 && S > 0 && S_total >= S && n >= 2 && n <= MAXC, "ucfvit_dice_ce_from_stats: bad sizes");
+    UCF_CHECK_ARG(dtype == UCFVIT_F32 || dtype == UCFVIT_BF16, "ucfvit_dice_ce_from_stats: bad dtype %d", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    // one "chunk" per batch element = the global sums themselves: the fold rewrites them in place and evaluates the loss
+    hipLaunchKernelGGL(dice_final, dim3(1), dim3(64), 0, s, (const float*)stats, stats, loss, (int)B, (int)n, S_total, 1, smooth_nr, smooth_dr);
+    if (dlogits) {
+        IN_DISPATCH(T, {
+            const dim3 g(apply_grid(S * 4, B), (unsigned)B);
+            hipLaunchKernelGGL((dice_bwd<T>), g, dim3(NT), 0, s, (const T*)logits, labels, (const float*)stats, (T*)dlogits, (int)B, (int)n, S,
+                               smooth_nr, smooth_dr, grad_scale, stride_b, stride_c, stride_s, S_total);
+        });
+    }
+    UCF_LAUNCH_CHECK("ucfvit_dice_ce_from_stats");
     return UCFVIT_OK;
 }
 
@@ -826,6 +869,52 @@ extern "C" int ucfvit_instnorm_cl_bwd(const void* dy, const void* y, const void*
         INCL_BWD_APPLY(false, false);
 #undef INCL_BWD_APPLY
     UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd");
+    return UCFVIT_OK;
+}
+
+// The backward pass in two calls, for a volume sharded across ranks (fsdp/sharded_decoder.py): _bwd_sums leaves the two per-(batch, channel)
+// MEANS over the local voxels (of dy' and of dy' xhat) in m1 / m2 [B][C]; the caller averages them over the group (equal slabs) and hands
+// them to _bwd_apply.  ucfvit_instnorm_cl_bwd = the two back to back.
+extern "C" int ucfvit_instnorm_cl_bwd_sums(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, float* m1, float* m2,
+                                           int64_t B, int64_t S, int64_t C, int64_t ld_dy, float slope, int had_res, void* workspace, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_bwd_sums", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(ld_dy >= C && ld_dy % 8 == 0 && ucf_is_aligned16(dy), "ucfvit_instnorm_cl_bwd_sums: ld_dy must be a multiple of 8 and >= C");
+    UCF_CHECK_ARG(dy && y && mean && rstd && m1 && m2 && workspace, "ucfvit_instnorm_cl_bwd_sums: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = cl_chunks_of(S, C);
+    const int64_t ldg8 = ld_dy / 8;
+    float* part = (float*)workspace;
+    if (had_res)
+        hipLaunchKernelGGL(incl_bwd_partial<true>, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
+                           part, S, (int)C, ch, slope, ldg8);
+    else
+        hipLaunchKernelGGL(incl_bwd_partial<false>, dim3(ch, (unsigned)B), dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd,
+                           part, S, (int)C, ch, slope, ldg8);
+    hipLaunchKernelGGL(incl_bwd_final, dim3((unsigned)(B * C)), dim3(64), 0, s, part, m1, m2, S, (int)C, ch);
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd_sums");
+    return UCFVIT_OK;
+}
+extern "C" int ucfvit_instnorm_cl_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* m1,
+                                            const float* m2, void* dx, void* dres, int64_t B, int64_t S, int64_t C, int64_t ld_dy, float slope,
+                                            int had_res, void* stream) {
+    if (int rc = incl_check("ucfvit_instnorm_cl_bwd_apply", x, B, S, C)) return rc;
+    UCF_CHECK_ARG(ld_dy >= C && ld_dy % 8 == 0 && ucf_is_aligned16(dy), "ucfvit_instnorm_cl_bwd_apply: ld_dy must be a multiple of 8 and >= C");
+    UCF_CHECK_ARG(dy && y && mean && rstd && m1 && m2 && dx, "ucfvit_instnorm_cl_bwd_apply: null pointer");
+    UCF_CHECK_ARG(had_res || !dres, "ucfvit_instnorm_cl_bwd_apply: dres without a residual in the forward pass");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ldg8 = ld_dy / 8;
+    const dim3 g(cl_apply_grid(S, C, B), (unsigned)B);
+#define INCL_BWD_APPLY(R_, W_)                                                                                                                  \
+    hipLaunchKernelGGL((incl_bwd_apply<R_, W_>), g, dim3(NT), 0, s, (const bf16*)dy, (const bf16*)y, (const bf16*)x, mean, rstd, m1, m2, (bf16*)dx, \
+                       (bf16*)(dres ? dres : dx), S, (int)C, slope, ldg8)
+    if (dres)
+        INCL_BWD_APPLY(true, true);
+    else if (had_res)
+        INCL_BWD_APPLY(true, false);
+    else
+        INCL_BWD_APPLY(false, false);
+#undef INCL_BWD_APPLY
+    UCF_LAUNCH_CHECK("ucfvit_instnorm_cl_bwd_apply");
     return UCFVIT_OK;
 }
 
