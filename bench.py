@@ -455,9 +455,18 @@ def build_workload(args, w, dev, rank, par=None):
         x = torch.rand(B, 1, *vol, generator=g).to(dev)
         labels = torch.randint(0, 4, (B, *vol), generator=g).to(dev)          # segmentation classes of every voxel, resident in HBM
 
+        sharded = par is not None and par["sp"] > 1 and model.shard_decoder()
+        if sharded:
+            # the decoder runs on X-slabs (fsdp/sharded_decoder.py): every rank holds its slab of the logits and of the labels
+            from UCF_VIT.fsdp import sharded_decoder as SD
+            labels_l = SD.local_slab(labels, par["spg"], 1).contiguous()
+
         def make_step(net, opt, sch):
             def step():
-                loss = HF.dice_ce(net(x, None), labels)                       # DiceCELoss(to_onehot_y, softmax, squared_pred), train_unetr_simple.py:38
+                if sharded:
+                    loss = SD.sharded_dice_ce(net(x, None), labels_l, par["spg"])
+                else:
+                    loss = HF.dice_ce(net(x, None), labels)                   # DiceCELoss(to_onehot_y, softmax, squared_pred), train_unetr_simple.py:38
                 loss.backward()
                 opt.step()
                 opt.zero_grad()
@@ -466,6 +475,8 @@ def build_workload(args, w, dev, rank, par=None):
             return step
         desc = ("UNETR train step (12-Block encoder on 8192 tokens with taps 3/6/9, skip-connection conv decoder feature_size 16 up to 512x512x128, "
                 "Dice+CE on 4 classes; fwd+bwd+AdamW), synthetic volumes and labels resident in HBM")
+        if sharded:
+            desc += "; encoder token shards AND decoder X-slabs sharded over the sequence-parallel group (halo exchange per 3x3x3 layer)"
         return model, make_step, B, desc, 1e-5
     for n_, p_ in model.named_parameters():        # encoder workload: the conv decoder takes no part
         if not n_.startswith(("blocks.", "patch_embed.", "token_embeds.", "norm.", "pos_embed")):

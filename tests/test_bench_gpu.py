@@ -52,7 +52,7 @@ def test_bench_config5_sequence_parallel_layout_self_launch():
     d = _bench(["--gpus", "2", "--sp", "2", "--steps", "2", "--warmup", "1", "--workload", "unetr_512x512x128", "--batch", "1", "--no-cpu-baseline"],
                {"UCFVIT_BENCH_BACKEND": "gloo", "UCFVIT_BENCH_ONE_GPU": "1"}, timeout=1200)
     _check(d, 2, "volumes/sec")
-    assert d["config"]["parallelism"] == "sp2(1x2)" and d["config"]["global_batch"] == 1
+    assert d["config"]["parallelism"] == "sp2(1x2)" and d["config"]["global_batch"] == 1 and "X-slabs" in d["config"]["workload"]
     assert 0.3 < d["config"]["final_loss"] < 5.0
 
 
