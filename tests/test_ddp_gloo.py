@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, bucket_mb, q):
+def _worker(rank, world, port, bucket_mb, q, algorithm="all_reduce"):
     for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -26,7 +26,7 @@ def _worker(rank, world, port, bucket_mb, q):
     kw = dict(img_size=[32, 32], patch_size=8, in_chans=3, num_classes=5, embed_dim=64, depth=2, num_heads=2)
     model = R.VIT(**kw)
     model.load_state_dict(det_state_dict(model, 100 + rank))       # ranks start DIFFERENT: wrap must broadcast rank 0's weights
-    ddp = HipDataParallel(model, bucket_mb=bucket_mb)
+    ddp = HipDataParallel(model, bucket_mb=bucket_mb, algorithm=algorithm)
     ref = R.VIT(**kw)
     ref.load_state_dict(det_state_dict(ref, 100))
     same = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
@@ -70,7 +70,26 @@ def test_reducer_two_ranks_gloo(bucket_mb, min_buckets):
         assert keys_ok and nb >= min_buckets
 
 
-def _hip_dp_worker(rank, world, port, q, reduce_dtype=None):
+@pytest.mark.parametrize("world", [2, 3])
+def test_reducer_direct_reduce_scatter_all_gather_gloo(world):
+    """algorithm="direct": the bucket's mean by all-to-all (chunk j to rank j) + fixed-order local sum + all-gather — the transport SURVEY §5
+    recommends for the fully connected xGMI node — equals the mean of the per-rank gradients; 3 ranks: bucket sizes that do not divide by
+    the world size (zero-padded chunks)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, 29541 + world, 0.05, q, "direct")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, keys_ok, nb in res:
+        assert ok, f"rank {rank}: gradients differ from the mean of per-rank gradients"
+        assert keys_ok and nb >= 3
+
+
+def _hip_dp_worker(rank, world, port, q, reduce_dtype=None, algorithm=None):
     for p in (os.path.join(ROOT, "ucf-vit_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -89,7 +108,7 @@ def _hip_dp_worker(rank, world, port, q, reduce_dtype=None):
         m = VIT(**kw)
         m.load_state_dict(det_state_dict(m, 100 + rank))        # different per rank: the wrap broadcasts rank 0's weights
         m = m.to("cuda:0")
-        ddp = HipDataParallel(m, bucket_mb=0.05, reduce_dtype=reduce_dtype)
+        ddp = HipDataParallel(m, bucket_mb=0.05, reduce_dtype=reduce_dtype, algorithm=algorithm)
         opt = configure_optimizer(m, 1e-3, 0.9, 0.95, 0.0)
         xs = [det_tensor((2, 3, 32, 32), 10 + r) for r in range(world)]
         ys = [torch.tensor([r % 5, (2 * r + 1) % 5]) for r in range(world)]
@@ -199,12 +218,15 @@ def test_hip_data_parallel_reduces_torch_produced_gradients_too():
 
 
 @pytest.mark.gpu
-def test_hip_data_parallel_two_ranks_share_one_gpu():
+@pytest.mark.parametrize("algorithm,reduce_dtype", [(None, None), ("direct", None), ("direct", "bf16")])
+def test_hip_data_parallel_two_ranks_share_one_gpu(algorithm, reduce_dtype):
     """the HIP model + flat-buffer reducer + fused AdamW with world_size 2 (both ranks on the one GPU, gloo transport):
-    gradients = mean over ranks, weights stay identical after the step"""
+    gradients = mean over ranks, weights stay identical after the step — with the default all-reduce and with the written-out
+    reduce-scatter + all-gather ("direct": all-to-all, fixed-order local sum, all-gather), fp32 and bf16 transport"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_hip_dp_worker, args=(r, 2, 29571, q)) for r in range(2)]
+    port = 29571 + (10 if algorithm else 0) + (1 if reduce_dtype else 0)
+    procs = [ctx.Process(target=_hip_dp_worker, args=(r, 2, port, q, reduce_dtype, algorithm)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(2)]

@@ -51,9 +51,19 @@ class _FlatGrads:
 
 
 class HipDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=32, broadcast_from=0, reduce_dtype=None):
+    def __init__(self, module, process_group=None, bucket_mb=32, broadcast_from=0, reduce_dtype=None, algorithm=None):
         super().__init__()
         self.module = module
+        # gradient transport of a bucket: "all_reduce" = one RCCL all-reduce (RCCL picks ring / tree / its own direct forms), "direct" =
+        # reduce-scatter + all-gather written out for a fully connected xGMI node: an all-to-all sends chunk j of the
+        # bucket to rank j over all 7 links at once (S/8 per link instead of a ring's 2 (P-1)/P S over one), every rank sums the P chunks
+        # it received in a fixed order (fp32) and an all-gather hands the means round the same way.  Same result as the all-reduce up to
+        # the summation order (fixed here).  UNMEASURED on hardware (no multi-GPU box in the build): opt-in, UCFVIT_DDP_ALGO=direct.
+        algo = algorithm or os.environ.get("UCFVIT_DDP_ALGO", "all_reduce")
+        if algo not in ("all_reduce", "direct"):
+            raise ValueError("HipDataParallel: algorithm must be 'all_reduce' or 'direct'")
+        self.algorithm = algo
+        self._cstream = None
         rd = reduce_dtype if reduce_dtype is not None else os.environ.get("UCFVIT_DDP_REDUCE_DTYPE")
         if isinstance(rd, str):
             rd = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[rd.lower()]
@@ -160,7 +170,39 @@ class HipDataParallel(nn.Module):
             self._comm = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
         return self._comm[lo:hi]
 
+    def _launch_direct(self, b):
+        """reduce-scatter by all-to-all + fixed-order local sum, then all-gather (see __init__); runs on a side stream on the GPU"""
+        lo, hi, _ = self.buckets[b]
+        view = self.flat_g[lo:hi]
+        P, n = self.world, hi - lo
+        m = -(-n // P)
+        rdt = self.reduce_dtype()
+        host = (not self._hip) or dist.get_backend(self.pg) == "gloo"
+        dev = torch.device("cpu") if host else view.device
+
+        def run():
+            send = torch.zeros(P * m, dtype=rdt, device=dev)
+            send[:n].copy_(view)                                             # (cast to the transport dtype; the tail pad stays zero)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.pg)                # chunk j of every rank's bucket lands on rank j
+            mine = recv.view(P, m).sum(dim=0, dtype=torch.float32).mul_(1.0 / P).to(rdt)     # fixed order: rank 0's chunk first
+            out = torch.empty(P * m, dtype=rdt, device=dev)
+            dist.all_gather_into_tensor(out, mine, group=self.pg)
+            view.copy_(out[:n])                                              # the mean, back in the fp32 gradient buffer
+
+        if host:
+            run()
+        else:
+            if self._cstream is None:
+                self._cstream = torch.cuda.Stream(device=view.device)
+            self._cstream.wait_stream(torch.cuda.current_stream())           # the bucket's gradients are complete on the compute stream
+            with torch.cuda.stream(self._cstream):
+                run()                                                        # RCCL work is stream-ordered behind / ahead of the glue kernels
+        self._pending[b] = -(1 << 30)
+
     def _launch(self, b):
+        if self.algorithm == "direct" and self.world > 1:
+            return self._launch_direct(b)
         lo, hi, _ = self.buckets[b]
         view = self.flat_g[lo:hi]
         bf16 = self.reduce_dtype() == torch.bfloat16
@@ -199,6 +241,8 @@ class HipDataParallel(nn.Module):
             if lo is not None:
                 _ops.cast(self._comm[lo:hi], self.flat_g[lo:hi])      # bf16 mean back into the fp32 gradient buffer
         self._works = []
+        if self._cstream is not None:
+            torch.cuda.current_stream().wait_stream(self._cstream)      # "direct" transport: the side stream's last copy-back
         self._callback_queued = False
 
     # ------------------------------------------------------------------ module API
