@@ -118,11 +118,11 @@ enum { S5_PLAIN = 1, S5_RESIDUAL = 2, S5_GELU_SAVE_DERIV = 5, S5_MUL_AUX = 6 };
 
 // The vector-memory operations one wave issues during an epilogue phase of E K-steps (4 E barrier intervals), in order, and the number
 // issued so far at every point that waits for one of them.  Interval u = 4 j + r:
-//   first interval of the last step: the 4 A pieces of the group's next tile (the B stream is fed by the partner group, which is in
-//            its K loop: a draining group's DMA waits would sit behind its own stores — vmcnt retires in order)
+//   r == 0 : (OWN_B, see EpiLog) the 4 DMA pieces of this group's half of the next B K-tile; in the last step the 4 A pieces of the
+//            group's next tile
 //   passes q of this interval (16 passes of 8 rows x 64 columns per wave tile; pass q runs in interval q * 4E / 16):
 //            input piece of pass q + PD, WAIT for the input of pass q (q >= PD), NS stores
-//   last interval: WAIT for those A pieces
+//   r == 2 : (OWN_B, G1) WAIT for the B pieces of this step     r == 3 : WAIT for every DMA piece of this step
 // The bias and the inputs of passes 0 .. PD-1 are loaded to registers at the start of the group's LAST K-step of the tile and have landed
 // behind that step's closing vmcnt(0): the phase opens without a memory round trip.
 template <int EPI, int E> struct EpiLog {
@@ -130,21 +130,24 @@ template <int EPI, int E> struct EpiLog {
     static constexpr bool HAS_IN = EPI == S5_RESIDUAL || EPI == S5_MUL_AUX;
     static constexpr int NS = EPI == S5_GELU_SAVE_DERIV ? 2 : 1;
     static constexpr int PD = 2;
-    // E == 1: the draining group feeds its own half of the B stream (its 4 pieces go out before any store of the phase, so the wait for
-    // them does not sit behind stores); E > 1: the partner group, which is in its K loop, feeds both halves (a draining group's wait for
-    // the pieces of step j would sit behind its stores of step j - 1: vmcnt retires in order)
-    static constexpr bool OWN_B = E == 1;
-    int idxL[16] = {}, idxDmaB = 0, idxDmaA = 0;
-    int nWL[16] = {}, nWB = 0, nWA = 0;
+    // Who feeds the draining group's half of the B stream?  OWN_B: the draining group itself, 4 pieces in the first interval of every one
+    // of its steps.  Its wait for the pieces of step j sits behind its stores of step j - 1 (vmcnt retires in order): harmless when those
+    // are old by then — one step (E == 1: no older stores at all) or long arithmetic slices (the GELU epilogue: a slice per interval, four
+    // intervals before the wait) — and a stall for the short slices of the other epilogues at E > 1, where the partner group, which is in
+    // its K loop, issues both halves instead.
+    static constexpr bool OWN_B = E == 1 || EPI == S5_GELU_SAVE_DERIV;
+    int idxL[16] = {}, idxDmaB[E] = {}, idxDmaAll[E] = {};
+    int nWL[16] = {}, nWB[E] = {}, nWD[E] = {};
     static constexpr int slot_of(int q) { return q * U / 16; }
     constexpr EpiLog() {
         int n = 0;
         for (int u = 0; u < U; ++u) {
-            if (u == U - 4) {            // first interval of the last step: (the B pieces,) the 4 A pieces of the group's next tile
+            const int j = u / 4, r = u % 4;
+            if (r == 0) {                // first interval of a step: (the B pieces,) in the last step the 4 A pieces of the group's next tile
                 if (OWN_B) n += 4;
-                idxDmaB = n;
-                n += 4;
-                idxDmaA = n;
+                idxDmaB[j] = n;
+                if (j == E - 1) n += 4;
+                idxDmaAll[j] = n;
             }
             for (int q = 0; q < 16; ++q) {
                 if (slot_of(q) != u) continue;
@@ -155,13 +158,13 @@ template <int EPI, int E> struct EpiLog {
                 nWL[q] = n;
                 n += NS;
             }
-            if (u == U - 2) nWB = n;
-            if (u == U - 1) nWA = n;
+            if (r == 2) nWB[j] = n;
+            if (r == 3) nWD[j] = n;
         }
     }
     constexpr int wait_in(int q) const { return nWL[q] - idxL[q]; }          // q >= PD only
-    constexpr int wait_b() const { return nWB - idxDmaB; }                   // OWN_B, G1: its B pieces one interval before the A pieces
-    constexpr int wait_a() const { return nWA - idxDmaA; }
+    constexpr int wait_b(int j) const { return nWB[j] - idxDmaB[j]; }        // OWN_B, G1: its B pieces one interval before everything else
+    constexpr int wait_all(int j) const { return nWD[j] - idxDmaAll[j]; }    // every DMA piece of step j (OWN_B: all steps; else the last)
 };
 
 template <int EPI, int E> inline constexpr EpiLog<EPI, E> kLog{};
@@ -354,9 +357,9 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
         constexpr int J = decltype(jc)::value;
         s5_for<0, 4>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value, u = 4 * J + r;
-            if constexpr (r == 0 && J == E - 1) {
+            if constexpr (r == 0) {
                 if constexpr (EpiLog<EPI, E>::OWN_B) s5_issue(bnext, offB, nb + A_BYTES, grp, w4);
-                s5_issue(anext, offA, nb, grp, w4);
+                if constexpr (J == E - 1) s5_issue(anext, offA, nb, grp, w4);
             }
             if constexpr (CS && u == 0) {
 #pragma unroll
@@ -366,10 +369,10 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
                 constexpr int q = decltype(qc)::value;
                 if constexpr (EpiLog<EPI, E>::slot_of(q) == u) pass(qc);
             });
-            if constexpr (EpiLog<EPI, E>::OWN_B && u == 4 * E - 2) {
-                if (grp == 1) s5_wait_vm<kLog<EPI, E>.wait_b()>();
+            if constexpr (EpiLog<EPI, E>::OWN_B && r == 2) {
+                if (grp == 1) s5_wait_vm<kLog<EPI, E>.wait_b(J)>();
             }
-            if constexpr (u == 4 * E - 1) s5_wait_vm<kLog<EPI, E>.wait_a()>();
+            if constexpr (r == 3 && (EpiLog<EPI, E>::OWN_B || J == E - 1)) s5_wait_vm<kLog<EPI, E>.wait_all(J)>();
             if constexpr (CS && u == 4 * E - 1) {
                 // lanes l, l + 8, ..., l + 56 hold the same 8 columns for different rows
 #pragma unroll
@@ -637,7 +640,7 @@ int ucfvit_gemm_stagger_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     // computing costs about what a paired K-step costs (the step is paced by the DMA round trip, not by the MFMAs), so the fewer such steps
     // the better: E = 1 wins everywhere it applies, larger E loses.  The residual epilogue only pays for itself behind a long K loop, and
     // the column-sum variant of the multiply epilogue does not fit the register budget at E = 1: both stay on gemm3_kernel.
-    int E = 1;
+    int E = 1;                                       // (fc1 forward with the GELU epilogue, E = 1 / 2 / 4 / 8: 1251 / 1262 / 1317 / 1652 us)
     if (ov > 0) E = ov;
     else if (epi == S5_RESIDUAL && nk < 32) return 0;
     else if (cs) return 0;
