@@ -19,7 +19,7 @@ workloads (BASELINE.json configs):
   unetr_512x512x128      configs[4], whole model: the encoder above + the skip-connection convolutional decoder (UnetrBasicBlock / UnetrPrUpBlock /
                          UnetrUpBlock, feature_size 16, simple/arch.py:808-940) on the HIP convolution kernels + Dice/CE loss
                          (train_unetr_simple.py:38) on 4 classes
-roofline: the dominant kernel family of the workload — the bf16 MFMA GEMM (gemm3_kernel, csrc/gemm2.hip) for the 224^2 workloads, the
+roofline: the dominant kernel family of the workload — the bf16 MFMA GEMM (gemm3_kernel in csrc/gemm2.hip and its staggered form gemm5_kernel in csrc/gemm_stagger.hip) for the 224^2 workloads, the
           streaming attention kernels (csrc/attention.hip) for the 8192-token encoder; `achieved` = algorithmic FLOPs of that family's
           launches in the timed region / their HIP-event-measured durations (events recorded on the launch stream).
 cpu_baseline: the CPU oracle's training loop (oracle/ucf_vit_ref.py, kind "port") on this box's host cores, rank 0, N=1 only.
@@ -659,8 +659,9 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         other = max((k for k in fam if k != dom), key=lambda k: fam[k]["ms"])
         kernel_names = {
-            "gemm": "gemm3_kernel<%s> 256x256x64 persistent ping-pong MFMA GEMM (every forward, data-gradient and grouped "
-                    "weight-gradient launch of the timed region)" % args.dtype,
+            "gemm": "gemm3_kernel<%s> / gemm5_kernel 256x256x64 persistent ping-pong MFMA GEMM (ping-pong: weight gradients, residual / "
+                    "column-sum epilogues; staggered ping-pong with the epilogue under the partner group's K loop: the other forward / "
+                    "data-gradient launches) — every ucfvit_gemm / ucfvit_gemm_grouped launch of the timed region" % args.dtype,
             "attention": "fused attention kernels (attn_fwd / attn_bwd_dq / attn_bwd_dkv streaming for N > 208, attn_s3_fwd / attn_g_bwd "
                          "resident below): every forward and backward launch of the timed region, algorithmic FLOPs 4 / 8 B H N^2 dh",
             "conv": "conv3_fwd_kernel / conv3_wgrad_kernel (csrc/conv3d.hip): 3x3x3 implicit-GEMM convolutions on MFMA, channels-last bf16 — every "

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FAMILIES = {
-    "gemm": re.compile(r"gemm3_kernel"),
+    "gemm": re.compile(r"gemm[35]_kernel"),
     "attention": re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|s3_fwd|g_bwd)"),
     "conv": re.compile(r"conv_(fwd|fwd_strip|wgrad)_kernel"),
 }

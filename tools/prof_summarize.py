@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 src, prefix = sys.argv[1], sys.argv[2]
 SHORT = {"vit_l16_224": ("vitl16", 665), "mae_vit_l16_224": ("mae_vitl16", 1002), "unetr_enc_512x512x128": ("unetr_enc", 2),
          "unetr_512x512x128": ("unetr", 2)}
-FAM = {"gemm": re.compile(r"gemm3_kernel"), "attention": re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|s3_fwd|g_bwd|delta)"),
+FAM = {"gemm": re.compile(r"gemm[35]_kernel"), "attention": re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|s3_fwd|g_bwd|delta)"),
        "conv": re.compile(r"conv_(fwd|fwd_strip|wgrad)_kernel")}
 
 
