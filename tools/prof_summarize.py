@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src, prefix = sys.argv[1], sys.argv[2]
-SHORT = {"vit_l16_224": ("vitl16", 665), "mae_vit_l16_224": ("mae_vitl16", 1002), "unetr_enc_512x512x128": ("unetr_enc", 2),
+SHORT = {"vit_l16_224": ("vitl16", 665), "vit_b16_224": ("vitb16", 1330), "vit_l16_adaptive196": ("vitl16_adaptive196", 665), "mae_vit_l16_224": ("mae_vitl16", 1002), "unetr_enc_512x512x128": ("unetr_enc", 2),
          "unetr_512x512x128": ("unetr", 2)}
 FAM = {"gemm": re.compile(r"gemm[35]_kernel"), "attention": re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|s3_fwd|g_bwd|delta)"),
        "conv": re.compile(r"conv_(fwd|fwd_strip|wgrad)_kernel")}
