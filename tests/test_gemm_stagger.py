@@ -1,7 +1,13 @@
 """The staggered ping-pong GEMM (csrc/gemm_stagger.hip: the epilogue of one wave group hidden under the partner group's K loop) against fp32
 products of the same bf16 operands, for every epilogue it implements and the shapes that stress its stream bookkeeping: ragged M, a
 ragged last N tile, tile counts below / above / not a multiple of the 256 workgroups, short K loops (fewer epilogue steps), long K loops.
+By default the library takes that kernel only for K >= 1024 (where it is faster): test_stagger_forced_variants re-runs this file in
+subprocesses with UCFVIT_GEMM_STAGGER = 1 / 2 / 4, which forces it — with that many epilogue steps — for every shape it can run.
 Reference call sites of these launches: /root/reference/src/UCF_VIT/simple/building_blocks.py:115-128,150-159,189-191."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
@@ -101,3 +107,15 @@ def test_stagger_strided_output_and_inputs():
     ref = x.float() @ w.float().T + b.float() + res_full[:, :N].float()
     assert _rel(out, ref) < 1e-2
     assert (out_full[:, N:] == 0).all()            # nothing written beyond the N columns of a row
+
+
+@pytest.mark.parametrize("steps", ["1", "2", "4"])
+def test_stagger_forced_variants(steps):
+    """every test of this file with the staggered kernel forced (also for the short-K shapes the default leaves to the ping-pong kernel) and
+    with 1 / 2 / 4 epilogue steps: the switch is read once per process, hence the subprocess"""
+    if os.environ.get("UCFVIT_GEMM_STAGGER"):
+        pytest.skip("already inside a forced run")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not forced_variants"],
+                       env=dict(os.environ, UCFVIT_GEMM_STAGGER=steps), capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -615,8 +615,11 @@ int ucfvit_gemm_stagger_try(const ucfvit_gemm_desc* d, hipStream_t s) {
         a.bias = (const bf16*)d->bias;
         a.bias_bytes = (unsigned)(d->N * 2);
     } else {
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_s5_zero_page)) != hipSuccess) return 0;
+        static void* const zp = [] {               // looked up once (thread-safe static); nullptr: this launch stays on gemm3_kernel
+            void* q = nullptr;
+            return hipGetSymbolAddress(&q, HIP_SYMBOL(g_s5_zero_page)) == hipSuccess ? q : nullptr;
+        }();
+        if (!zp) return 0;
         a.bias = (const bf16*)zp;
         a.bias_bytes = 0;                                   // every lane out of range: the bias reads as zero
     }
@@ -640,8 +643,12 @@ int ucfvit_gemm_stagger_try(const ucfvit_gemm_desc* d, hipStream_t s) {
     // computing costs about what a paired K-step costs (the step is paced by the DMA round trip, not by the MFMAs), so the fewer such steps
     // the better: E = 1 wins everywhere it applies, larger E loses.  The residual epilogue only pays for itself behind a long K loop, and
     // the column-sum variant of the multiply epilogue does not fit the register budget at E = 1: both stay on gemm3_kernel.
+    // Which launches: per-shape A/B at the shapes of all five workloads (profiles/r03_c_stagger_shapes.txt): the staggered kernel wins
+    // 3-7 % at K >= 1536, 0-6 % at K = 1024 and LOSES 4-10 % at K = 768 / 512 (the cyclic re-read of a B K-tile and the two unpaired steps
+    // per tile weigh 1 / nk): K >= 1024 only.
     int E = 1;                                       // (fc1 forward with the GELU epilogue, E = 1 / 2 / 4 / 8: 1251 / 1262 / 1317 / 1652 us)
     if (ov > 0) E = ov;
+    else if (nk < 16) return 0;
     else if (epi == S5_RESIDUAL && nk < 32) return 0;
     else if (cs) return 0;
     if (nk < 2 * E) E = nk >= 8 ? 4 : (nk >= 4 ? 2 : (nk >= 2 ? 1 : 0));
