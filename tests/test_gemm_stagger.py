@@ -109,6 +109,33 @@ def test_stagger_strided_output_and_inputs():
     assert (out_full[:, N:] == 0).all()            # nothing written beyond the N columns of a row
 
 
+def test_stagger_random_shapes():
+    """seeded random shapes (M ragged, N any multiple of 8, K any multiple of 64, tile counts around the 192-tile threshold of the 256x256
+    kernels and around multiples of the 256 workgroups), every epilogue, against fp32 products of the same bf16 operands"""
+    import random
+    rng = random.Random(20251005)
+    g = torch.Generator().manual_seed(99)
+    for _ in range(10):
+        tn = rng.choice([1, 2, 3, 4, 5, 9])
+        N = tn * 256 - rng.choice([0, 0, 8, 128, 248])
+        tm = max(2, rng.choice([192, 200, 256, 300, 520]) // tn + rng.choice([0, 1]))
+        M = tm * 256 - rng.randrange(0, 255)
+        K = 64 * rng.choice([2, 3, 5, 8, 16, 17, 24, 40])
+        x, w, b = _rnd(g, M, K), _rnd(g, N, K, scale=0.05), _rnd(g, N)
+        ref = x.float() @ w.float().T + b.float()
+        tag = f"M={M} N={N} K={K}"
+        assert _rel(ops.linear_fwd(x, w, b), ref) < 1e-2, tag
+        res = _rnd(g, M, N)
+        assert _rel(ops.linear_fwd(x, w, b, residual=res), ref + res.float()) < 1e-2, tag
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        y = ops.linear_fwd(x, w, b, act=ACT_GELU_SAVE_DERIV, aux_out=aux)
+        gr, dr = _gelu_ref(ref)
+        assert _rel(y, gr) < 1e-2 and _rel(aux, dr) < 1e-2, tag
+        yd = ops.linear_dgrad_t(x, w, act_grad_aux=res, aux_is_deriv=True)
+        assert _rel(yd, (x.float() @ w.float().T) * res.float()) < 1e-2, tag
+        del x, w, b, ref, res, aux, y, yd, gr, dr
+
+
 @pytest.mark.parametrize("steps", ["1", "2", "4"])
 def test_stagger_forced_variants(steps):
     """every test of this file with the staggered kernel forced (also for the short-K shapes the default leaves to the ping-pong kernel) and
