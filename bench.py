@@ -685,7 +685,7 @@ def main():
             "config": {"workload": f"{args.workload} {desc}",
                        "per_gpu_batch": B, "global_batch": B * dp, "parallelism": parallelism, "final_loss": round(final_loss, 4),
                        "per_group_batch_note": None if par is None else "per_gpu_batch is the batch of one sequence- / tensor-parallel group (its ranks share it)",
-                       "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, " + ("RCCL" if backend == "nccl" else backend + " (rehearsal)") + ", overlapped with backward") if world > 1 else "none (1 rank)"},
+                       "grad_all_reduce": (str(net.reduce_dtype()).replace("torch.", "") + " mean, " + ("RCCL" if backend == "nccl" else backend + " (rehearsal)") + ", overlapped with backward" + (", direct reduce-scatter + all-gather (UCFVIT_DDP_ALGO=direct)" if getattr(net, "algorithm", "") == "direct" else "")) if world > 1 else "none (1 rank)"},
             "roofline": {"bound": "mfma", "kernel": kernel_names[dom],
                          "achieved": round(d["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
                          "traffic": traffic, "traffic_note": traffic_src, "launches": d["launches"],
