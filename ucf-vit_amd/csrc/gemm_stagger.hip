@@ -198,6 +198,20 @@ __device__ __forceinline__ void s5_tile_origin(int t, int tiles_m, int tiles_n, 
     n0 = (band * BAND + in_band % band_w) * 256;
 }
 
+// first half of an epilogue pass (see gemm5_kernel: `pass`): stage strip Q / 2 (even Q), read rows (Q & 1) * 8 + prow back transposed.
+// (A free function, not a lambda: hipcc does not capture the operands of an asm statement inside a generic lambda that is instantiated
+// from within another generic lambda.)
+template <int Q>
+__device__ __forceinline__ void s5_pass_fetch(unsigned st_w, unsigned st_r, const f32x4 (&acc)[8][4], f32x4 (&plo)[2], f32x4 (&phi)[2]) {
+    constexpr int i = Q >> 1, ps = Q & 1, PADW = 68;
+    if constexpr (ps == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(st_w), "v"(acc[i][j]), "i"(64 * j) : "memory");
+    }
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(plo[Q & 1]) : "v"(st_r), "i"(ps * 8 * PADW * 4) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(phi[Q & 1]) : "v"(st_r), "i"(ps * 8 * PADW * 4 + 16) : "memory");
+}
+
 template <int EPI, bool CS, int E>
 __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
@@ -278,34 +292,33 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
         __builtin_amdgcn_s_setprio(0);                                                             \
     } while (0)
 
-    // one pass of the epilogue: rows ps * 8 + prow of strip i, 8 columns per lane
-    auto pass = [&](auto qc) __attribute__((always_inline)) {
-        constexpr int q = decltype(qc)::value, i = q >> 1, ps = q & 1;
-        if constexpr (ps == 0) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(st_w), "v"(acc[i][j]), "i"(64 * j) : "memory");
-        }
+    // One pass of the epilogue: rows ps * 8 + prow of strip i, 8 columns per lane.  Two halves so that the LDS round trip of pass q + 1
+    // (stage the strip, read it back transposed) is in flight under the arithmetic of pass q:
+    //   pass_fetch<q>: [even q: the 4 ds_write_b128 of strip q / 2]  the input piece of pass q + PD  2 ds_read_b128 -> plo / phi[q & 1]
+    //   pass_math<q, AHEAD>: wait for those reads leaving the AHEAD younger LDS operations (the fetch of pass q + 1) in flight, arithmetic, stores
+    f32x4 plo[2], phi[2];
+    auto pass = [&](auto qc, auto aheadc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value, i = q >> 1, ps = q & 1, AHEAD = decltype(aheadc)::value;
         if constexpr (HAS_IN && q + PD < 16) {
             constexpr int qn = q + PD;
             const int mrow = em + 16 * (qn >> 1) + 8 * (qn & 1);
             const unsigned vo = (mrow < a.M && nok) ? voIn + (unsigned)((16 * (qn >> 1) + 8 * (qn & 1)) * a.ldin * 2) : S5_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rIn, (lptr_t)(inring + (qn % (PD + 1)) * 1024), 16, vo, 0, 0, 0);
         }
-        f32x4 lo, hi;
         u32x4 hin = {0u, 0u, 0u, 0u};
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo) : "v"(st_r), "i"(ps * 8 * PADW * 4) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hi) : "v"(st_r), "i"(ps * 8 * PADW * 4 + 16) : "memory");
         if constexpr (HAS_IN && q >= PD) {
             constexpr int WAIT_IN = kLog<EPI, E>.wait_in(q);
             static_assert(WAIT_IN >= 0 && WAIT_IN <= 63, "vmcnt is a 6-bit count");
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_IN) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hin) : "v"(in_r), "i"((q % (PD + 1)) * 1024) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi), "+v"(hin)::"memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo[q & 1]), "+v"(phi[q & 1]), "+v"(hin)::"memory");
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+            // LDS operations of one wave complete in order: AHEAD counts the ones issued after this pass's two reads (compiler-issued scalar
+            // loads in between could only make the wait stricter)
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(plo[q & 1]), "+v"(phi[q & 1]) : "n"(AHEAD) : "memory");
             if constexpr (HAS_IN) hin = early[q];
         }
+        const f32x4 lo = plo[q & 1], hi = phi[q & 1];
         float v[8];
         if constexpr (EPI == S5_MUL_AUX) {       // (data gradients carry no bias)
 #pragma unroll
@@ -367,7 +380,13 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
             }
             s5_for<0, 16>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (EpiLog<EPI, E>::slot_of(q) == u) pass(qc);
+                if constexpr (EpiLog<EPI, E>::slot_of(q) == u) {
+                    constexpr bool first = q == 0 || EpiLog<EPI, E>::slot_of(q - 1) != u;
+                    constexpr bool more = q + 1 < 16 && EpiLog<EPI, E>::slot_of(q + 1) == u;
+                    if constexpr (first) s5_pass_fetch<q>(st_w, st_r, acc, plo, phi);
+                    if constexpr (more) s5_pass_fetch<q + 1>(st_w, st_r, acc, plo, phi);   // in flight under this pass's arithmetic
+                    pass(qc, IC<(more ? (((q + 1) & 1) == 0 ? 6 : 2) : 0)>{});
+                }
             });
             if constexpr (EpiLog<EPI, E>::OWN_B && r == 2) {
                 if (grp == 1) s5_wait_vm<kLog<EPI, E>.wait_b(J)>();
