@@ -395,12 +395,13 @@ def test_gemm_row_padded_operands(dtype):
         assert rel_err(dw, dy.double().T @ x.double()) < (1e-5 if dtype == torch.float32 else 1e-4)
 
 
-@pytest.mark.parametrize("N,dh", [(197, 64), (196, 32), (120, 64), (100, 32), (50, 64), (17, 32), (208, 32), (230, 64), (230, 32)])
+@pytest.mark.parametrize("N,dh", [(197, 64), (196, 32), (120, 64), (100, 32), (50, 64), (17, 32), (208, 32), (230, 64), (230, 32), (256, 64),
+                                  (209, 64), (16, 64), (33, 32), (100, 64), (1, 64)])
 def test_attention_kernels_all_short_sequence_paths(N, dh):
     """bf16 attention forward + backward against fp32 softmax(QK^T/sqrt(dh))V on the SAME bf16 inputs, over every dispatch of the
-    short-sequence kernels: fused resident forward (N <= 208) / resident forward (N <= 256) and the fused backward for 4 / 8 / 13
-    blocks of 16 tokens, head dims 64 and 32; N = 230 takes the streaming backward.  Tolerance 2e-2 of the largest reference
-    magnitude (bf16 probabilities and outputs)."""
+    short-sequence kernels: fused resident forward (N <= 208) / resident forward (N <= 256) and the fused backward for 4 / 8 / 13 / 16
+    blocks of 16 tokens (two blocks per wave pass: even and odd block counts, a single block, a single token), head dims 64 and 32.
+    Tolerance 2e-2 of the largest reference magnitude (bf16 probabilities and outputs)."""
     from UCF_VIT._hip import ops
     B, H = 3, 2
     gen = torch.Generator().manual_seed(N * 100 + dh)

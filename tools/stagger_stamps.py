@@ -11,7 +11,7 @@ out_dir = os.path.join(ROOT, "gpurun_out", "stamps")
 os.makedirs(out_dir, exist_ok=True)
 lib = os.path.join(out_dir, "libucfvit_stamp.so")
 objs = [os.path.join(PKG, "build", f) for f in os.listdir(os.path.join(PKG, "build")) if f.endswith(".o") and f != "gemm_stagger.o"]
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-DS5_STAMP", "-c",
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-DS5_STAMP", *__import__("shlex").split(os.environ.get("S5_EXTRA", "")), "-c",
                 os.path.join(PKG, "csrc", "gemm_stagger.hip"), "-o", os.path.join(out_dir, "gemm_stagger_stamp.o")], check=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, os.path.join(out_dir, "gemm_stagger_stamp.o")] + objs, check=True)
 os.environ["UCFVIT_HIP_LIB"] = lib

@@ -21,8 +21,8 @@
 // attention_short.hip: whole-sequence-in-LDS kernels for N <= 256 (return 1 = handled, 0 = not applicable, <0 = error)
 int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
                                hipStream_t s);
-int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
-                               float scale, int dtype, hipStream_t s);
+int ucfvit_attention_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H,
+                               int64_t dh, float scale, int dtype, hipStream_t s);
 
 
 namespace {
@@ -764,9 +764,9 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N
 template <typename T, int DH>
 int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int64_t B, int64_t N,
                     int64_t H, float scale, hipStream_t s) {
-    // the FUSED backward (one launch, operands read once, delta taken from P and dP inside) is the default where it applies
+    // the FUSED backward (one launch, operands read once, delta = rowsum(dO o O) taken inside) is the default where it applies
     {
-        const int rc = ucfvit_attention_fused_bwd(qkv, dout, lse, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
+        const int rc = ucfvit_attention_fused_bwd(qkv, out, dout, lse, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;
     }

@@ -233,13 +233,20 @@ int launch_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int
     return UCFVIT_OK;
 }
 // =====================================================================================================================
-// backward, fused (bf16, head dim 64, N <= 208): ONE launch per attention layer instead of delta + dQ + dK/dV.
+// backward, fused (bf16, head dim 64 / 32, N <= 256): ONE launch per attention layer instead of delta + dQ + dK/dV.
 // Phase A: each wave takes query blocks and produces dQ with K and V resident in LDS; phase B: each wave takes key blocks and
 // produces dK, dV with Q and dO resident — the two formulations of the two-kernel backward, without the 64-row tile padding
 // (13 x 13 blocks of 16 instead of 16 x 16 for N = 197) and without the re-reads of Q / dO per key tile.
+//
+// A wave works on TWO 16-row blocks at a time where the sequence has more than 8 blocks (every K / V fragment read from LDS in phase A,
+// every Q / dO fragment in phase B feeds two MFMAs: 1372 KiB of LDS reads per head at N = 197 instead of 2444), and the score tiles are
+// made and consumed per 32-row chunk instead of being kept for a whole row — no register array grows with the sequence, so N <= 256 fits
+// (16 blocks; the first form stopped at 13).  For that delta = rowsum(dO o O) comes from the forward output (read once in phase A, handed
+// to phase B through LDS) instead of from a whole row of P and dP.
+// What bounds the kernel is not its arithmetic (measured at ViT-L B = 665, 16 heads, N = 197: with 6/7 of the chunk loop removed it still
+// took 711 of 888 us) but the workgroup's chain of global-memory round trips, see AgOpsA below and profiles/r03_f_attention_bwd.txt.
 // Every LDS address is one of six per-lane bases plus an immediate (row images: base ^ 64 c + 2048 block; transposed reads:
-// base ^ 32 d + 4096 chunk) and sched_barriers keep hipcc from hoisting all fragment reads of a phase: 218 VGPRs, no spills
-// (the earlier resident dQ / dKdV kernels spilled 124-564 bytes per lane and were slower than the streaming kernels).
+// base ^ 32 d + 4096 chunk); sched_barriers keep hipcc from hoisting all fragment reads of a phase.
 // =====================================================================================================================
 template <int RB> __device__ __forceinline__ bf16x8 af_row(const char* img, int base_c, int blk) {   // rows 16 blk .. + 15, k-chunk c
     return *reinterpret_cast<const bf16x8*>(img + base_c + blk * (16 * RB));
@@ -291,6 +298,21 @@ __device__ __forceinline__ void ag_fetch(AgStage<ROWS, DH>& st, const bf16* __re
         if (p < ROWS * SPR && row < R) st.v[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + slot * 8);
     }
 }
+// All global accesses of the fused backward are RAW BUFFER loads / stores whose resource covers rows [0, N) of one (batch, head): rows >= N
+// are out of range for the hardware (loads return 0, stores are dropped), so there is no branch around any of them and hipcc's
+// s_waitcnt bookkeeping stays exact — a load requested a pass ahead is waited for with vmcnt(number of younger stores), not vmcnt(0).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ag_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+template <int ROWS, int DH>
+__device__ __forceinline__ void ag_fetch(AgStage<ROWS, DH>& st, __amdgpu_buffer_rsrc_t r, int byte0, int row_bytes, int tid) {
+    constexpr int SPR = DH / 8;
+#pragma unroll
+    for (int i = 0; i < AgStage<ROWS, DH>::NIT; ++i) {
+        const int p = tid + i * AG_THREADS;
+        st.v[i] = __builtin_amdgcn_raw_buffer_load_b128(r, byte0 + (p / SPR) * row_bytes + (p % SPR) * 16, 0, 0);
+    }
+}
 template <int ROWS, int DH> __device__ __forceinline__ void ag_store(const AgStage<ROWS, DH>& st, char* lds, int tid) {
     constexpr int SPR = DH / 8;
 #pragma unroll
@@ -300,18 +322,263 @@ template <int ROWS, int DH> __device__ __forceinline__ void ag_store(const AgSta
     }
 }
 
-template <int DH, int NB, bool EXACT>
-__global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                                 const float* __restrict__ lse, bf16* __restrict__ dqkv, int N, int H,
-                                                                 float scale, float scale_log2e) {
+__device__ __forceinline__ bf16x8 ag_pack(const f32x4& lo, const f32x4& hi) {    // two 16-row accumulator blocks -> one 32-deep operand
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (bf16)lo[j];
+        r[4 + j] = (bf16)hi[j];
+    }
+    return r;
+}
+
+#ifdef AG_STAMP
+// diagnostic build (tools/attn_stamps.py; never part of the product library): every wave of one workgroup in the middle of the grid
+// records the shader clock at the phase boundaries
+__device__ unsigned long long g_ag_stamps[4][32];
+#define AG_STAMP_HERE(k)                                                                                        \
+    do {                                                                                                        \
+        if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) g_ag_stamps[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define AG_STAMP_HERE(k) do { } while (0)
+#endif
+
+template <int DH, int NB, bool EXACT> struct AgCtx {
+    static constexpr int RB = DH * 2, NCH = DH / 32, NDB = DH / 16, NRC = (NB + 1) / 2;
+    const char *slot0, *slot1;
+    const float *ldsLse, *ldsDelta;
+    int rowb[NCH], trb, N, g, li, lane;
+    float scale, sl2;
+};
+
+// Operands a wave holds in registers for one pass: NJ 16-row blocks of (Q, dO, O) in phase A, of (K, V) in phase B.  A pass's operands are
+// requested one pass AHEAD (the first phase-A pass with the K / V images at kernel start, the first phase-B pass from the K / V images in
+// LDS before Q / dO replace them), so a workgroup's global-memory round trips are the images and nothing else: with the operand fetch at
+// the top of every pass the kernel ran at 711 us per ViT-L layer (B = 665) even with 6/7 of its arithmetic removed, against 420 us for
+// the same bytes moved by a kernel that only loads and stores (tools/attn_mem_pattern.hip).
+template <int NJ, int NCH> struct AgOpsA {
+    bf16x8 qf[NJ][NCH], dof[NJ][NCH], of[NJ][NCH];
+};
+template <int NJ, int NCH> struct AgOpsB {
+    bf16x8 kf[NJ][NCH], vf[NJ][NCH];
+};
+
+template <int DH> __device__ __forceinline__ bf16x8 ag_frag(__amdgpu_buffer_rsrc_t r, int byte0, int row, int row_bytes, int c, int lane) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte0 + row * row_bytes + (4 * c + (lane >> 4)) * 16, 0, 0));
+}
+template <int NJ, int DH>
+__device__ __forceinline__ void ag_a_fetch(AgOpsA<NJ, DH / 32>& o, int blk0, __amdgpu_buffer_rsrc_t rQ, int rs_bytes, __amdgpu_buffer_rsrc_t rDO,
+                                           __amdgpu_buffer_rsrc_t rO, int d_bytes, int li, int lane) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (blk0 + j) * 16 + li;
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c) {
+            o.qf[j][c] = ag_frag<DH>(rQ, 0, q, rs_bytes, c, lane);
+            o.dof[j][c] = ag_frag<DH>(rDO, 0, q, d_bytes, c, lane);
+            o.of[j][c] = ag_frag<DH>(rO, 0, q, d_bytes, c, lane);
+        }
+    }
+}
+template <int NJ, int DH>
+__device__ __forceinline__ void ag_b_fetch(AgOpsB<NJ, DH / 32>& o, int blk0, __amdgpu_buffer_rsrc_t rQ, int rs_bytes, int d_bytes, int li, int lane) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int key = (blk0 + j) * 16 + li;
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c) {
+            o.kf[j][c] = ag_frag<DH>(rQ, d_bytes, key, rs_bytes, c, lane);
+            o.vf[j][c] = ag_frag<DH>(rQ, 2 * d_bytes, key, rs_bytes, c, lane);
+        }
+    }
+}
+__device__ __forceinline__ void ag_store4(__amdgpu_buffer_rsrc_t r, int byte_off, const f32x4& v, float mul) {
+    Vec4<bf16> o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.set(i, v[i] * mul);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), r, byte_off, 0, 0);
+}
+
+// phase A for the query blocks blk0 .. blk0 + NJ - 1: K in slot 0, V in slot 1.  -delta is the initial value of the dP accumulator, so
+// dS = P o (dP - delta) is one multiply.
+template <int NJ, int DH, int NB, bool EXACT>
+__device__ __forceinline__ void ag_dq_pass(const AgCtx<DH, NB, EXACT>& cx, int blk0, const AgOpsA<NJ, DH / 32>& o, float* __restrict__ ldsDeltaW,
+                                           __amdgpu_buffer_rsrc_t rDQ, int rs_bytes) {
     typedef bf16 T;
-    constexpr int RB = DH * 2, NCH = DH / 32, NDB = DH / 16, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * RB;
+    typedef AgCtx<DH, NB, EXACT> C;
+    constexpr int RB = C::RB, NCH = C::NCH, NDB = C::NDB, NRC = C::NRC;
+    const int N = cx.N, g = cx.g, li = cx.li;
+    float neg_lse[NJ], neg_delta[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (blk0 + j) * 16 + li;
+        float dl = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dl = fmaf((float)o.dof[j][c][i], (float)o.of[j][c][i], dl);
+        neg_delta[j] = -gsum(dl);                      // delta[q] = sum_d dO[q][d] O[q][d]; the lanes li, li + 16, .. hold the row's slots
+        neg_lse[j] = -cx.ldsLse[q];
+        if (g == 0) ldsDeltaW[q] = neg_delta[j];       // phase B reads -delta (after the barrier between the phases)
+    }
+    f32x4 dq[NJ][NDB];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) dq[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rc = 0; rc < NRC; ++rc) {
+        f32x4 dst[NJ][2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int kb = 2 * rc + h2;
+            if (kb < NB) {
+                bf16x8 kfr[NCH], vfr[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    kfr[c] = af_row<RB>(cx.slot0, cx.rowb[c], kb);
+                    vfr[c] = af_row<RB>(cx.slot1, cx.rowb[c], kb);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {neg_delta[j], neg_delta[j], neg_delta[j], neg_delta[j]};
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        MmaS<T>::mma(sacc, kfr[c], o.qf[j][c]);
+                        MmaS<T>::mma(dp, vfr[c], o.dof[j][c]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], cx.sl2, neg_lse[j]));
+                        if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) p = (kb * 16 + 4 * g + r < N) ? p : 0.f;     // ragged key block only
+                        dst[j][h2][r] = p * dp[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) dst[j][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        bf16x8 f[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f[j] = ag_pack(dst[j][0], dst[j][1]);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const bf16x8 ktr = af_tr<RB>(cx.slot0, cx.trb ^ (d << 5), rc);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) MmaS<T>::mma(dq[j][d], ktr, f[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef AG_STAMP
+        if (blk0 < AG_WAVES * NJ) AG_STAMP_HERE(17 + rc);
+        else AG_STAMP_HERE(24 + rc);
+#endif
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (blk0 + j) * 16 + li;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) ag_store4(rDQ, q * rs_bytes + d * 32 + 8 * g, dq[j][d], cx.scale);       // rows >= N: dropped by the range check
+    }
+}
+
+// phase B for the key blocks blk0 .. blk0 + NJ - 1: Q in slot 0, dO in slot 1
+template <int NJ, int DH, int NB, bool EXACT>
+__device__ __forceinline__ void ag_dkv_pass(const AgCtx<DH, NB, EXACT>& cx, int blk0, const AgOpsB<NJ, DH / 32>& o, __amdgpu_buffer_rsrc_t rDQ, int rs_bytes,
+                                            int d_bytes) {
+    typedef bf16 T;
+    typedef AgCtx<DH, NB, EXACT> C;
+    constexpr int RB = C::RB, NCH = C::NCH, NDB = C::NDB, NRC = C::NRC;
+    const int N = cx.N, g = cx.g, li = cx.li;
+    f32x4 dk[NJ][NDB], dv[NJ][NDB];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            dk[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int rc = 0; rc < NRC; ++rc) {
+        f32x4 pt[NJ][2], st[NJ][2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int qb = 2 * rc + h2;
+            if (qb < NB) {
+                bf16x8 qfr[NCH], dofr[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    qfr[c] = af_row<RB>(cx.slot0, cx.rowb[c], qb);
+                    dofr[c] = af_row<RB>(cx.slot1, cx.rowb[c], qb);
+                }
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(cx.ldsLse + qb * 16 + 4 * g);         // +inf on padding queries: P = 0
+                const f32x4 nd4 = *reinterpret_cast<const f32x4*>(cx.ldsDelta + qb * 16 + 4 * g);      // -delta of the rows 4 g .. 4 g + 3
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = nd4;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        MmaS<T>::mma(sacc, qfr[c], o.kf[j][c]);
+                        MmaS<T>::mma(dp, dofr[c], o.vf[j][c]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], cx.sl2, -l4[r]));
+                        pt[j][h2][r] = p;
+                        st[j][h2][r] = p * dp[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    pt[j][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    st[j][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        bf16x8 fp[NJ], fs[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            fp[j] = ag_pack(pt[j][0], pt[j][1]);
+            fs[j] = ag_pack(st[j][0], st[j][1]);
+        }
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            const bf16x8 dotr = af_tr<RB>(cx.slot1, cx.trb ^ (d << 5), rc);
+            const bf16x8 qtr = af_tr<RB>(cx.slot0, cx.trb ^ (d << 5), rc);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                MmaS<T>::mma(dv[j][d], dotr, fp[j]);
+                MmaS<T>::mma(dk[j][d], qtr, fs[j]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int key = (blk0 + j) * 16 + li;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            ag_store4(rDQ, d_bytes + key * rs_bytes + d * 32 + 8 * g, dk[j][d], cx.scale);
+            ag_store4(rDQ, 2 * d_bytes + key * rs_bytes + d * 32 + 8 * g, dv[j][d], 1.f);
+        }
+    }
+}
+
+// NJ blocks per pass: 2 where a wave has more than one block per phase anyway (N > 128), 1 below that (every wave keeps a block)
+template <int DH, int NB, bool EXACT>
+__global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
+    typedef bf16 T;
+    constexpr int RB = DH * 2, NCH = DH / 32, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * RB, NJ = NB > 8 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* slot0 = smem;                 // K, then Q
     char* slot1 = smem + IMG;           // V, then dO
     float* ldsLse = reinterpret_cast<float*>(smem + 2 * IMG);   // [ROWS]
     float* ldsDelta = ldsLse + ROWS;
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % H;
     const int64_t b = blockIdx.x / H;
@@ -319,153 +586,81 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
     const int64_t rs = 3 * (int64_t)D;
     const T* qbase = qkv + b * N * rs + h * DH;
     const T* dobase = dout + b * N * (int64_t)D + h * DH;
+    const T* obase = out + b * N * (int64_t)D + h * DH;
+    T* dqbase = dqkv + b * N * rs + h * DH;
     const float* lse_bh = lse + (b * H + h) * N;
+    const int nqb = (N + 15) / 16;
+    constexpr int STEP = AG_WAVES * NJ;                 // blocks between a wave's two passes (N <= 256: never more than two per phase)
+    const int rs_bytes = (int)rs * 2, d_bytes = D * 2;
+    const __amdgpu_buffer_rsrc_t rQ = ag_rsrc(qbase, N * rs_bytes), rDO = ag_rsrc(dobase, N * d_bytes), rO = ag_rsrc(obase, N * d_bytes),
+                                 rDQ = ag_rsrc(dqbase, N * rs_bytes);
+    AG_STAMP_HERE(0);
+    AgOpsA<NJ, NCH> oa, oa2;
+    ag_a_fetch<NJ, DH>(oa, wave * NJ, rQ, rs_bytes, rDO, rO, d_bytes, li, lane);     // first phase-A pass: requested with the images
     {
         AgStage<ROWS, DH> sk, sv;
-        ag_fetch<ROWS, DH>(sk, qbase + D, rs, N, tid);
-        ag_fetch<ROWS, DH>(sv, qbase + 2 * D, rs, N, tid);
+        ag_fetch<ROWS, DH>(sk, rQ, d_bytes, rs_bytes, tid);
+        ag_fetch<ROWS, DH>(sv, rQ, 2 * d_bytes, rs_bytes, tid);
         ag_store<ROWS, DH>(sk, slot0, tid);
         ag_store<ROWS, DH>(sv, slot1, tid);
     }
+    AG_STAMP_HERE(1);
     for (int i = tid; i < ROWS; i += AG_THREADS) {
         ldsLse[i] = i < N ? lse_bh[i] : INFINITY;    // +inf -> P = 0 for padding queries
-        ldsDelta[i] = 0.f;                           // phase A fills the blocks that exist
+        ldsDelta[i] = 0.f;                           // phase A fills the blocks that exist (with -delta)
     }
     AgStage<ROWS, DH> sq, sdo;                           // phase B's images travel while phase A computes
-    ag_fetch<ROWS, DH>(sq, qbase, rs, N, tid);
-    ag_fetch<ROWS, DH>(sdo, dobase, D, N, tid);
+    ag_fetch<ROWS, DH>(sq, rQ, 0, rs_bytes, tid);
+    ag_fetch<ROWS, DH>(sdo, rDO, 0, d_bytes, tid);
+    ag_a_fetch<NJ, DH>(oa2, wave * NJ + STEP, rQ, rs_bytes, rDO, rO, d_bytes, li, lane);   // second pass (out of range where there is none)
     __syncthreads();
+    AG_STAMP_HERE(2);
 
     const AfBases<DH> ab(lane);
-    const int trb = ab.trb;
-    constexpr int nb_ = NB;
-    const int nqb = (N + 15) / 16;
+    AgCtx<DH, NB, EXACT> cx;
+    cx.slot0 = slot0;
+    cx.slot1 = slot1;
+    cx.ldsLse = ldsLse;
+    cx.ldsDelta = ldsDelta;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cx.rowb[c] = ab.rowb[c];
+    cx.trb = ab.trb;
+    cx.N = N;
+    cx.g = lane >> 4;
+    cx.li = li;
+    cx.lane = lane;
+    cx.scale = scale;
+    cx.sl2 = scale_log2e;
 
-    // ---------------- phase A: dQ (K in slot 0, V in slot 1) -----------------------------------------------------------
-    for (int qb = wave; qb < nqb; qb += AG_WAVES) {
-        const int q = qb * 16 + li;
-        bf16x8 qf[NCH], dof[NCH];
+    // ---------------- phase A: dQ (K in slot 0, V in slot 1) ----------------------------------------------------------
+    ag_dq_pass<NJ>(cx, wave * NJ, oa, ldsDelta, rDQ, rs_bytes);
+    AG_STAMP_HERE(3);
+    if (wave * NJ + STEP < nqb) ag_dq_pass<NJ>(cx, wave * NJ + STEP, oa2, ldsDelta, rDQ, rs_bytes);
+    AG_STAMP_HERE(4);
+    // the first phase-B pass's K / V blocks come out of the images before Q / dO replace them (reverse wave order in phase B)
+    const int bw = AG_WAVES - 1 - wave;
+    AgOpsB<NJ, NCH> ob, ob2;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
-            dof[c] = s_frag_global<T, DH>(dobase, D, q, N, c, lane);
+            ob.kf[j][c] = *reinterpret_cast<const bf16x8*>(slot0 + cx.rowb[c] + (bw * NJ + j) * (16 * RB));
+            ob.vf[j][c] = *reinterpret_cast<const bf16x8*>(slot1 + cx.rowb[c] + (bw * NJ + j) * (16 * RB));
         }
-        const float my_lse = ldsLse[q];
-        // delta[q] = sum_d dO[q][d] O[q][d] = sum_k P[q][k] dP[q][k]: taken here from the P and dP this wave holds anyway (one row of
-        // queries per lane column), so the separate delta kernel and its read of O and dO are not needed
-        f32x4 ds[NB], dpk[NB];
-        float dl = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                MmaS<T>::mma(sacc, af_row<RB>(slot0, ab.rowb[c], kb), qf[c]);
-                MmaS<T>::mma(dp, af_row<RB>(slot1, ab.rowb[c], kb), dof[c]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -my_lse));
-                if (EXACT ? (kb == NB - 1) : (kb * 16 + 16 > N)) p = (kb * 16 + 4 * g + r < N) ? p : 0.f;     // ragged key block only
-                ds[kb][r] = p;
-                dl = fmaf(p, dp[r], dl);
-            }
-            dpk[kb] = dp;
-            if (kb & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        const float my_delta = gsum(dl);
-        if (g == 0) ldsDelta[q] = my_delta;           // phase B reads it (after the barrier between the phases)
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ds[kb][r] *= dpk[kb][r] - my_delta;
-        f32x4 dq[NDB];
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int rc = 0; rc < NRC; ++rc) {
-            const bf16x8 f = s_frag_acc<T, nb_>(ds, rc);
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) MmaS<T>::mma(dq[d], af_tr<RB>(slot0, trb ^ (d << 5), rc), f);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (q < N) {
-            T* op = dqkv + (b * N + q) * rs + h * DH;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) {
-                Vec4<T> v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v.set(r, dq[d][r] * scale);
-                *reinterpret_cast<Vec4<T>*>(op + d * 16 + 4 * g) = v;
-            }
-        }
-    }
+    AG_STAMP_HERE(8);
     __syncthreads();                     // every wave is done with K and V
+    AG_STAMP_HERE(9);
     ag_store<ROWS, DH>(sq, slot0, tid);
     ag_store<ROWS, DH>(sdo, slot1, tid);
+    ag_b_fetch<NJ, DH>(ob2, bw * NJ + STEP, rQ, rs_bytes, d_bytes, li, lane);          // second phase-B pass: in flight under the first
     __syncthreads();
+    AG_STAMP_HERE(10);
 
-    // ---------------- phase B: dK, dV (Q in slot 0, dO in slot 1), reverse wave order -----------------------------------
-    for (int kb = AG_WAVES - 1 - wave; kb < nqb; kb += AG_WAVES) {
-        const int key = kb * 16 + li;
-        bf16x8 kf[NCH], vf[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            kf[c] = s_frag_global<T, DH>(qbase + D, rs, key, N, c, lane);
-            vf[c] = s_frag_global<T, DH>(qbase + 2 * D, rs, key, N, c, lane);
-        }
-        f32x4 pm[NB], ds[NB];
-#pragma unroll
-        for (int qb = 0; qb < NB; ++qb) {
-            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                MmaS<T>::mma(sacc, af_row<RB>(slot0, ab.rowb[c], qb), kf[c]);
-                MmaS<T>::mma(dp, af_row<RB>(slot1, ab.rowb[c], qb), vf[c]);
-            }
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsLse + qb * 16 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsDelta + qb * 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -l4[r]));
-                pm[qb][r] = p;
-                ds[qb][r] = p * (dp[r] - d4[r]);
-            }
-            if (qb & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 dk[NDB], dv[NDB];
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int rc = 0; rc < NRC; ++rc) {
-            const bf16x8 fp = s_frag_acc<T, nb_>(pm, rc);
-            const bf16x8 fs = s_frag_acc<T, nb_>(ds, rc);
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) {
-                MmaS<T>::mma(dv[d], af_tr<RB>(slot1, trb ^ (d << 5), rc), fp);
-                MmaS<T>::mma(dk[d], af_tr<RB>(slot0, trb ^ (d << 5), rc), fs);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (key < N) {
-            T* kp = dqkv + (b * N + key) * rs + D + h * DH;
-            T* vp = kp + D;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) {
-                Vec4<T> a, c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    a.set(r, dk[d][r] * scale);
-                    c.set(r, dv[d][r]);
-                }
-                *reinterpret_cast<Vec4<T>*>(kp + d * 16 + 4 * g) = a;
-                *reinterpret_cast<Vec4<T>*>(vp + d * 16 + 4 * g) = c;
-            }
-        }
-    }
+    // ---------------- phase B: dK, dV (Q in slot 0, dO in slot 1), reverse wave order ----------------------------------
+    ag_dkv_pass<NJ>(cx, bw * NJ, ob, rDQ, rs_bytes, d_bytes);
+    AG_STAMP_HERE(11);
+    if (bw * NJ + STEP < nqb) ag_dkv_pass<NJ>(cx, bw * NJ + STEP, ob2, rDQ, rs_bytes, d_bytes);
+    AG_STAMP_HERE(16);
 }
 
 
@@ -492,10 +687,20 @@ __global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* 
     const int D = H * DH;
     const int64_t rs = 3 * (int64_t)D;
     const T* qbase = qkv + b * N * rs + h * DH;
+    // the query blocks of ALL the wave's passes are requested with the images (range-checked buffer loads: rows >= N read as 0): the
+    // workgroup has one global-memory round trip instead of one per pass
+    constexpr int NPASS = (NB + AG_WAVES - 1) / AG_WAVES;
+    const int rs_bytes = (int)rs * 2;
+    const __amdgpu_buffer_rsrc_t rQ = ag_rsrc(qbase, N * rs_bytes);
+    bf16x8 qf_all[NPASS][NCH];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) qf_all[i][c] = ag_frag<DH>(rQ, 0, (wave + i * AG_WAVES) * 16 + li, rs_bytes, c, lane);
     {
         AgStage<ROWS, DH> sk, sv;
-        ag_fetch<ROWS, DH>(sk, qbase + D, rs, N, tid);
-        ag_fetch<ROWS, DH>(sv, qbase + 2 * D, rs, N, tid);
+        ag_fetch<ROWS, DH>(sk, rQ, D * 2, rs_bytes, tid);
+        ag_fetch<ROWS, DH>(sv, rQ, 2 * D * 2, rs_bytes, tid);
         ag_store<ROWS, DH>(sk, ldsK, tid);
         ag_store<ROWS, DH>(sv, ldsV, tid);
     }
@@ -504,11 +709,14 @@ __global__ __launch_bounds__(AG_THREADS, 3) void attn_s3_fwd_kernel(const bf16* 
     const int trb = ab.trb;
     constexpr int nb_ = NB;
     const int nqb = (N + 15) / 16;
-    for (int qb = wave; qb < nqb; qb += AG_WAVES) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int qb = wave + ps * AG_WAVES;
+        if (qb >= nqb) break;
         const int q = qb * 16 + li;
         bf16x8 qf[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) qf[c] = s_frag_global<T, DH>(qbase, rs, q, N, c, lane);
+        for (int c = 0; c < NCH; ++c) qf[c] = qf_all[ps][c];
         f32x4 s[NB];
         float mx = -INFINITY;
 #pragma unroll
@@ -577,18 +785,19 @@ int launch_s3_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, 
 }
 
 template <int DH, int NB>
-int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+int launch_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, float scale,
+                     hipStream_t s) {
     constexpr int ROWS = ((NB + 1) / 2) * 32;
     constexpr size_t smem = 2 * (size_t)ROWS * (DH * 2) + 2 * ROWS * sizeof(float);
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)(B * H)), block(AG_THREADS);
     if ((N + 15) / 16 == NB) {
         if (int rc = big_lds(attn_g_bwd_kernel<DH, NB, true>, smem)) return rc;
-        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
                            (int)H, scale, sl2);
     } else {
         if (int rc = big_lds(attn_g_bwd_kernel<DH, NB, false>, smem)) return rc;
-        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
                            (int)H, scale, sl2);
     }
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(fused)");
@@ -596,6 +805,12 @@ int launch_fused_bwd(const void* qkv, const void* dout, const float* lse, void* 
 }
 
 }  // namespace
+
+#ifdef AG_STAMP
+extern "C" int ucfvit_debug_attn_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ag_stamps), sizeof(unsigned long long) * 4 * 32);
+}
+#endif
 
 // returns 1 when handled, 0 when the shape is outside the short-sequence kernels (caller streams), <0 on error
 #define AS_PICK(FN, T, DH, ...)                          \
@@ -618,16 +833,17 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
     AS_PICK(launch_fwd, bf16, 32, qkv, out, lse, B, N, H, scale, s);
 }
 
-// fused backward (bf16, head dim 64 or 32, N <= 208; needs no delta): 1 = handled, 0 = not applicable, <0 = error
-int ucfvit_attention_fused_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, int64_t dh,
-                               float scale, int dtype, hipStream_t s) {
-    if (dtype != UCFVIT_BF16 || N > 208 || (dh != 64 && dh != 32) || B * H >= (1ll << 31)) return 0;   // 14..16 blocks would spill: streaming pair
+// fused backward (bf16, head dim 64 or 32, N <= 256; needs no delta workspace): 1 = handled, 0 = not applicable, <0 = error
+int ucfvit_attention_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H,
+                               int64_t dh, float scale, int dtype, hipStream_t s) {
+    if (dtype != UCFVIT_BF16 || N > 256 || (dh != 64 && dh != 32) || B * H >= (1ll << 31)) return 0;
     const int nb = (int)((N + 15) / 16);
     int rc;
-#define AF_BWD(DH_)                                                                            \
-    (nb <= 4 ? launch_fused_bwd<DH_, 4>(qkv, dout, lse, dqkv, B, N, H, scale, s)               \
-             : nb <= 8 ? launch_fused_bwd<DH_, 8>(qkv, dout, lse, dqkv, B, N, H, scale, s)     \
-                       : launch_fused_bwd<DH_, 13>(qkv, dout, lse, dqkv, B, N, H, scale, s))
+#define AF_BWD(DH_)                                                                                       \
+    (nb <= 4 ? launch_fused_bwd<DH_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, s)                     \
+             : nb <= 8 ? launch_fused_bwd<DH_, 8>(qkv, out, dout, lse, dqkv, B, N, H, scale, s)           \
+                       : nb <= 13 ? launch_fused_bwd<DH_, 13>(qkv, out, dout, lse, dqkv, B, N, H, scale, s) \
+                                  : launch_fused_bwd<DH_, 16>(qkv, out, dout, lse, dqkv, B, N, H, scale, s))
     rc = dh == 64 ? AF_BWD(64) : AF_BWD(32);
 #undef AF_BWD
     return rc == UCFVIT_OK ? 1 : rc;

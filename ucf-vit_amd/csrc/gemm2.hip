@@ -20,6 +20,15 @@ int ucfvit_gemm_stagger_try(const ucfvit_gemm_desc* d, hipStream_t s);   // gemm
 
 namespace {
 
+// C / aux tiles are written once and not read again by this kernel: stored with the non-temporal hint, the dirty lines leave L2 as the
+// K loop's fills need the ways instead of in one write-back burst one L2 turnover later (4 MB of C per XCD and tile round).
+#ifndef UCFVIT_GEMM_STORE_TEMPORAL
+__device__ __forceinline__ void store_out16(bf16* p, const Vec16<bf16>& o) { __builtin_nontemporal_store(o.v, reinterpret_cast<bf16x8*>(p)); }
+#else
+__device__ __forceinline__ void store_out16(bf16* p, const Vec16<bf16>& o) { *reinterpret_cast<Vec16<bf16>*>(p) = o; }
+#endif
+
+
 constexpr int BK2 = 64;
 
 __device__ __forceinline__ int kc_off2(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
                         Vec16<bf16> o;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                        *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                        store_out16(ep.aux_out + (int64_t)m * ep.ldaux + n, o);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
                     }
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
                     Vec16<bf16> o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, df[r]);
-                    *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                    store_out16(ep.aux_out + (int64_t)m * ep.ldaux + n, o);
                 } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
                     const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
 #pragma unroll
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const bf16* __restri
                     Vec16<bf16> o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                    *reinterpret_cast<Vec16<bf16>*>(cp) = o;
+                    store_out16(cp, o);
                 } else {
                     f32x4 o0, o1;
 #pragma unroll
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                             Vec16<bf16> o;
 #pragma unroll
                             for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                            if (inside) *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                            if (inside) store_out16(ep.aux_out + (int64_t)m * ep.ldaux + n, o);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = o.get(r);   // activation sees the stored (rounded) pre-activation
                         }
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                         Vec16<bf16> o;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) o.set(r, df[r]);
-                        if (inside) *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                        if (inside) store_out16(ep.aux_out + (int64_t)m * ep.ldaux + n, o);
                     } else if constexpr (EPI == EPI_GELU_GRAD) {
                         float hf[8];
 #pragma unroll
@@ -828,7 +837,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                     Vec16<bf16> o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                    if (inside) *reinterpret_cast<Vec16<bf16>*>(C + (int64_t)m * ldc + n) = o;
+                    if (inside) store_out16(C + (int64_t)m * ldc + n, o);
                     if constexpr (CS) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) csum[r] += inside ? v[r] : 0.f;
@@ -900,7 +909,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                         Vec16<bf16> o;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                        *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                        store_out16(ep.aux_out + (int64_t)m * ep.ldaux + n, o);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = o.get(r);
                     }
@@ -917,7 +926,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                     Vec16<bf16> o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, df[r]);
-                    *reinterpret_cast<Vec16<bf16>*>(ep.aux_out + (int64_t)m * ep.ldaux + n) = o;
+                    store_out16(ep.aux_out + (int64_t)m * ep.ldaux + n, o);
                 } else if (ep.act == UCFVIT_ACT_MUL_AUX) {
                     const Vec16<bf16> h = *reinterpret_cast<const Vec16<bf16>*>(ep.aux_in + (int64_t)m * ep.ldaux + n);
 #pragma unroll
@@ -938,7 +947,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GroupsT<NP> gt, int K, Epi2 
                     Vec16<bf16> o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o.set(r, v[r]);
-                    *reinterpret_cast<Vec16<bf16>*>(cp) = o;
+                    store_out16(cp, o);
                 } else {
                     f32x4 o0, o1;
 #pragma unroll

@@ -27,6 +27,10 @@
 
 #include "common.h"
 
+#ifndef S5_ST_MOD
+#define S5_ST_MOD " nt"      // C / aux are written once: non-temporal, so the dirty lines leave L2 gradually (see gemm2.hip:store_out16)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) o.set(r, df[r]);
             const unsigned vo = inside ? voAux + rowoff * (unsigned)(a.ldaux * 2) : S5_OOB;
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(o.v), "v"(vo), "s"(rAux) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" S5_ST_MOD "\n\ts_nop 1" ::"v"(o.v), "v"(vo), "s"(rAux) : "memory");
         } else if constexpr (EPI == S5_MUL_AUX || EPI == S5_RESIDUAL) {
             const bf16x8 h = __builtin_bit_cast(bf16x8, hin);
 #pragma unroll
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) o.set(r, v[r]);
         const unsigned vo = inside ? voC + rowoff * (unsigned)(a.ldc * 2) : S5_OOB;
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(o.v), "v"(vo), "s"(rC) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" S5_ST_MOD "\n\ts_nop 1" ::"v"(o.v), "v"(vo), "s"(rC) : "memory");
         if constexpr (CS) {
             const float keep = inside ? 1.0f : 0.0f;
 #pragma unroll
@@ -413,6 +417,30 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
         });
     };
 
+    // last K-step of a group's tile: set the epilogue phase up and fetch what its first passes need
+    auto epi_setup = [&]() __attribute__((always_inline)) {
+        etm0 = m0;
+        etn0 = n0;
+        em = m0 + wm + prow;
+        const int ncol = n0 + wn + pcol;
+        nok = ncol < a.N;
+        voC = (unsigned)(((int64_t)em * a.ldc + ncol) * 2);
+        voIn = (unsigned)(((int64_t)em * a.ldin + ncol) * 2);
+        voAux = (unsigned)(((int64_t)em * a.ldaux + ncol) * 2);
+        if constexpr (EPI != S5_MUL_AUX) {
+            const unsigned vb = nok ? (unsigned)(ncol * 2) : S5_OOB;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(biasw) : "v"(vb), "s"(rBias) : "memory");
+        }
+        if constexpr (HAS_IN) {
+#pragma unroll
+            for (int qn = 0; qn < PD; ++qn) {
+                const int mrow = em + 16 * (qn >> 1) + 8 * (qn & 1);
+                const unsigned vo = (mrow < a.M && nok) ? voIn + (unsigned)((16 * (qn >> 1) + 8 * (qn & 1)) * a.ldin * 2) : S5_OOB;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(early[qn]) : "v"(vo), "s"(rInR) : "memory");
+            }
+        }
+    };
+
     int s = 0;                       // stream step counter: step s lives in pipeline buffer s & 1
     if (grp == 1) s5_barrier();      // G1 runs one barrier interval behind G0 (ping-pong of the paired K-steps)
     for (int c = 0;; ++c) {
@@ -423,8 +451,9 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
         if (next_ok) tile_mn(c + 1, nm0, nn0);
 #pragma clang loop unroll(disable)
         for (int p = 0; p < plen; ++p, ++s) {
-            if (p == E && tile_ok && nk - 1 > E) {
-                // ---- the bulk of the tile: steps E .. nk-2, both groups in their K loop, nothing changes but the K position.
+            if (p == E && tile_ok && nk > E) {
+                // ---- the bulk of the tile: steps E .. nk-1, both groups in their K loop (G0 on k = p, G1 on the same stream step of
+                // its own rows), nothing changes but the K position; in the last of them G0 prepares its drain and fetches no A.
                 // (Kept apart from the general step below: its mode / operand bookkeeping per step is scalar work in front of
                 // G0's DMA issue, on the critical path of the paired K-steps.)
                 if (grp == 1) {
@@ -434,12 +463,15 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
                         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma clang loop unroll(disable)
-                for (; p < nk - 1; ++p, ++s) {
+                for (; p < nk; ++p, ++s) {
                     const char* bufA = smem + (s & 1) * BUF;
                     const char* bufB = bufA + A_BYTES;
                     char* nb = smem + ((s + 1) & 1) * BUF;
-                    s5_issue(a.B + (p + 1) * 128, offB, nb + A_BYTES, grp, w4);
-                    s5_issue(a.A + (p + 1) * 128, offA, nb, grp, w4);
+                    const bool g0_last = grp == 0 && p == nk - 1;
+                    const int kn = p == nk - 1 ? 0 : p + 1;            // the B panel is streamed cyclically
+                    if (g0_last) epi_setup();
+                    s5_issue(a.B + kn * 128, offB, nb + A_BYTES, grp, w4);
+                    if (!g0_last) s5_issue(a.A + kn * 128, offA, nb, grp, w4);
                     S5_READ(bufA, bufB, 0);
                     s5_barrier();
                     S5_COMPUTE();
@@ -448,7 +480,10 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
                     if (grp == 1) s5_wait_vm<4>();
                     s5_barrier();
                     S5_COMPUTE();
-                    s5_wait_vm<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (PD == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(biasw), "+v"(early[0]), "+v"(early[1])::"memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(biasw), "+v"(early[0])::"memory");
+                    __builtin_amdgcn_sched_barrier(0);
                     s5_barrier();
                 }
             }
@@ -472,35 +507,13 @@ __global__ __launch_bounds__(512) void gemm5_kernel(StaggerArgs a) {
             if (knext && (grp == 0 ? pn == 0 : pn == E)) s5_offsets(offA, a.lda, wrap ? nm0 : m0, a.M, grp, w4, lane);
             const char* anext = a.A + (knext ? kb * 128 : 0);
             if (kmode) {
-                if (grp == 0 ? p == 0 : (p == E && !(nk - 1 > E))) {
+                if (grp == 0 ? p == 0 : (p == E && !(nk > E))) {
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (grp == 0 ? p == nk - 1 : p == nk + E - 1) {
-                    // last K-step of this group's tile: set the epilogue phase up and fetch what its first passes need
-                    etm0 = m0;
-                    etn0 = n0;
-                    em = m0 + wm + prow;
-                    const int ncol = n0 + wn + pcol;
-                    nok = ncol < a.N;
-                    voC = (unsigned)(((int64_t)em * a.ldc + ncol) * 2);
-                    voIn = (unsigned)(((int64_t)em * a.ldin + ncol) * 2);
-                    voAux = (unsigned)(((int64_t)em * a.ldaux + ncol) * 2);
-                    if constexpr (EPI != S5_MUL_AUX) {
-                        const unsigned vb = nok ? (unsigned)(ncol * 2) : S5_OOB;
-                        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(biasw) : "v"(vb), "s"(rBias) : "memory");
-                    }
-                    if constexpr (HAS_IN) {
-#pragma unroll
-                        for (int qn = 0; qn < PD; ++qn) {
-                            const int mrow = em + 16 * (qn >> 1) + 8 * (qn & 1);
-                            const unsigned vo = (mrow < a.M && nok) ? voIn + (unsigned)((16 * (qn >> 1) + 8 * (qn & 1)) * a.ldin * 2) : S5_OOB;
-                            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(early[qn]) : "v"(vo), "s"(rInR) : "memory");
-                        }
-                    }
-                }
+                if (grp == 0 ? p == nk - 1 : p == nk + E - 1) epi_setup();
                 s5_issue(bnext, offB, nb + A_BYTES, grp, w4);
                 if constexpr (!EpiLog<EPI, E>::OWN_B) {
                     if (grp == 0 ? p < E : p >= nk) s5_issue(bnext, offB2, nb + A_BYTES, grp ^ 1, w4);     // the partner drains: its half too
