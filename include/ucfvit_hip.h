@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 9
+#define UCFVIT_ABI_VERSION 10
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -422,6 +422,8 @@ int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void* x, const 
  *   in the same pass, so the concatenation is written as whole rows.
  * ucfvit_pad_channels8: fp32 N C D H W input [B][C][S] with C <= 8 -> bf16 channels-last [B][S][8] (channels C..7 zero): the input volume as
  *   an operand of the kernels above.
+ * ucfvit_pad_rows8: V rows of C <= 8 values (src_dtype UCFVIT_F32 or UCFVIT_BF16, row stride ld elements) -> dense bf16 [V][8], columns C..7
+ *   zero: the gradient of the output head's logits (_hip/conv.py:Conv1x1x1Fn.backward) as an operand of the kernels above, in one pass.
  * ------------------------------------------------------------------------------------------------------ */
 int ucfvit_conv3d_fwd(const void* x, const void* w_packed, const float* bias, void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
                       int64_t Cout, int ksize, int64_t ldy, int64_t cout_store, int out_dtype, int accumulate, float* stats_partial, void* stream);
@@ -435,6 +437,7 @@ int ucfvit_conv3d_wgrad(const void* x, const void* dy, float* dw_packed, void* w
 int ucfvit_depth_to_space2(const void* src, void* dst, int64_t B, int64_t Xi, int64_t Yi, int64_t Zi, int64_t C, int64_t ld_space, int to_space,
                            const void* skip, int64_t Cs, void* stream);
 int ucfvit_pad_channels8(const float* src, void* dst, int64_t B, int64_t C, int64_t S, void* stream);
+int ucfvit_pad_rows8(const void* src, int src_dtype, void* dst, int64_t V, int64_t C, int64_t ld, void* stream);
 
 #ifdef __cplusplus
 }

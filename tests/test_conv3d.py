@@ -145,6 +145,28 @@ torch.save(out, sys.argv[1])
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pad_rows8_dense_rows_and_channel_slices(dtype):
+    """narrow channels-last rows -> bf16 rows of 8 (ucfvit_pad_rows8): dense [.., 4], a 4-channel slice of a 16-channel buffer, the permuted
+    [B, n, X, Y, Z] view the Dice / CE gradient arrives as; bit-exact against a torch cast, zero padding; rows without a common stride raise"""
+    from UCF_VIT._hip import ops
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(2, 5, 6, 7, 4, generator=g).to(dtype).cuda()
+    o = ops.pad_rows8(a)
+    assert o.shape == (2, 5, 6, 7, 8) and o.dtype == torch.bfloat16 and o.is_contiguous()
+    assert torch.equal(o[..., :4], a.bfloat16()) and o[..., 4:].abs().max() == 0
+    wide = torch.randn(2, 5, 6, 7, 16, generator=g).to(dtype).cuda()
+    o2 = ops.pad_rows8(wide[..., 8:11])
+    assert torch.equal(o2[..., :3], wide[..., 8:11].bfloat16()) and o2[..., 3:].abs().max() == 0
+    ncdhw_view = a.permute(0, 4, 1, 2, 3)                    # what the loss hands back; the head's backward sees movedim(1, -1) of it
+    assert torch.equal(ops.pad_rows8(ncdhw_view.movedim(1, -1)), o)
+    with pytest.raises(ValueError):
+        ops.pad_rows8(a[:, ::2])
+    with pytest.raises(TypeError):
+        ops.pad_rows8(torch.zeros(4, 9, device="cuda"))
+
+
+@pytest.mark.gpu
 def test_conv3x3x3_single_channel_input_through_the_padded_operand():
     from UCF_VIT._hip import conv, ops
     g = torch.Generator().manual_seed(3)

@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
 GEMM_SCHED_BYTES = 1024
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
@@ -98,6 +98,7 @@ SIGNATURES = {
     "ucfvit_conv3d_wgrad": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "ucfvit_depth_to_space2": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P, _I64, _P]),
     "ucfvit_pad_channels8": (c_int, [_P, _P, _I64, _I64, _I64, _P]),
+    "ucfvit_pad_rows8": (c_int, [_P, c_int, _P, _I64, _I64, _I64, _P]),
     "ucfvit_cross_entropy": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P]),
     "ucfvit_mae_mask": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "ucfvit_gather_rows": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),

@@ -589,7 +589,8 @@ def dice_ce(logits, labels, smooth_nr=1e-5, smooth_dr=1e-5, grad_scale=1.0, want
         if not ok:
             raise RuntimeError("dice_ce: logits must be contiguous or a channels-last view with contiguous voxel rows")
         sb, sc, ss = S * ld, 1, ld
-        dl = torch.zeros(B * S * ld, dtype=logits.dtype, device=logits.device).as_strided(logits.shape, logits.stride()) if want_grad else None
+        mk = torch.empty if ld == n else torch.zeros                 # padding columns of the rows, if any, read as zero gradient
+        dl = mk(B * S * ld, dtype=logits.dtype, device=logits.device).as_strided(logits.shape, logits.stride()) if want_grad else None
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
     ws = workspace(L.ucfvit_dice_ce_workspace(B, S), logits.device)
     _l.check(L.ucfvit_dice_ce_strided(logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dl), B, n, S, sb, sc, ss, smooth_nr, smooth_dr,
@@ -645,7 +646,8 @@ def dice_ce_from_stats(logits, labels, stats, S_total, smooth_nr=1e-5, smooth_dr
         if logits.is_contiguous():
             dl = torch.empty_like(logits)
         else:
-            dl = torch.zeros(B * sb, dtype=logits.dtype, device=logits.device).as_strided(logits.shape, logits.stride())
+            mk = torch.empty if ss == n else torch.zeros             # padding columns of the rows, if any, read as zero gradient
+            dl = mk(B * sb, dtype=logits.dtype, device=logits.device).as_strided(logits.shape, logits.stride())
     else:
         dl = None
     stats = stats.clone()                                # rewritten in place by the fold
@@ -796,6 +798,24 @@ def pad_channels8(vol):
     B, C = vol.shape[0], vol.shape[1]
     out = torch.empty((B,) + tuple(vol.shape[2:]) + (8,), dtype=torch.bfloat16, device=vol.device)
     _l.check(L.ucfvit_pad_channels8(vol.data_ptr(), out.data_ptr(), B, C, vol.numel() // (B * C), _stream()), "ucfvit_pad_channels8")
+    return out
+
+
+def pad_rows8(t):
+    """[..., C <= 8] fp32 or bf16 with contiguous voxel rows (element stride 1 in the last axis, one row stride ld >= C for all the others:
+    a dense tensor or a channel slice of a wider channels-last buffer) -> dense bf16 [..., 8], columns C..7 zero"""
+    L = _l.load()
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16) or t.shape[-1] > 8 or t.stride(-1) != 1:
+        raise TypeError("pad_rows8: expected a CUDA fp32 / bf16 tensor with at most 8 contiguous channels in the last axis")
+    ld = t.stride(-2) if t.dim() > 1 else t.shape[-1]
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError("pad_rows8: the leading axes must form one run of rows with a common stride")
+        exp *= t.shape[d]
+    V = t.numel() // t.shape[-1]
+    out = torch.empty(tuple(t.shape[:-1]) + (8,), dtype=torch.bfloat16, device=t.device)
+    _l.check(L.ucfvit_pad_rows8(t.data_ptr(), dt(t), out.data_ptr(), V, t.shape[-1], ld, _stream()), "ucfvit_pad_rows8")
     return out
 
 

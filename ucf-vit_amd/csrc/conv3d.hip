@@ -682,6 +682,17 @@ __global__ __launch_bounds__(CT) void pad8_kernel(const float* __restrict__ src,
     }
 }
 
+// rows of C <= 8 values (fp32 or bf16, row stride ld elements) -> dense bf16 rows of 8, columns C..7 zero: a narrow channels-last gradient (the
+// logits' gradient of the output head) as an operand of the MFMA kernels, in one pass instead of a fill and a strided cast copy
+template <typename S> __global__ __launch_bounds__(CT) void padrow8_kernel(const S* __restrict__ src, bf16* __restrict__ dst, int64_t V, int C, int64_t ld) {
+    for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < V; i += (int64_t)gridDim.x * CT) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(e < C ? (float)src[i * ld + e] : 0.f);
+        reinterpret_cast<bf16x8*>(dst)[i] = o;
+    }
+}
+
 int conv_check(const char* name, const void* x, const void* w, const void* y, int64_t B, int64_t X, int64_t Y, int64_t Z, int64_t Cin,
                int64_t Cout, int ksize) {
     UCF_CHECK_ARG(x && w && y, "%s: null pointer", name);
@@ -969,5 +980,18 @@ extern "C" int ucfvit_pad_channels8(const float* src, void* dst, int64_t B, int6
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(pad8_kernel, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, src, (bf16*)dst, B, (int)C, S);
     UCF_LAUNCH_CHECK("ucfvit_pad_channels8");
+    return UCFVIT_OK;
+}
+
+extern "C" int ucfvit_pad_rows8(const void* src, int src_dtype, void* dst, int64_t V, int64_t C, int64_t ld, void* stream) {
+    UCF_CHECK_ARG(src && dst && V > 0 && C >= 1 && C <= 8 && ld >= C && ucf_is_aligned16(dst), "ucfvit_pad_rows8: need 1 <= C <= 8 and ld >= C");
+    UCF_CHECK_ARG(src_dtype == UCFVIT_F32 || src_dtype == UCFVIT_BF16, "ucfvit_pad_rows8: source must be fp32 or bf16");
+    int64_t blocks = (V + CT - 1) / CT;
+    if (blocks > 65536) blocks = 65536;
+    if (src_dtype == UCFVIT_F32)
+        hipLaunchKernelGGL(padrow8_kernel<float>, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, (const float*)src, (bf16*)dst, V, (int)C, ld);
+    else
+        hipLaunchKernelGGL(padrow8_kernel<bf16>, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, V, (int)C, ld);
+    UCF_LAUNCH_CHECK("ucfvit_pad_rows8");
     return UCFVIT_OK;
 }
