@@ -236,7 +236,7 @@ class KernelProfiler:
         # the recompute of S and dP inside the backward kernels is not credited
         ops.attention_fwd = self._timed("attention", ops.attention_fwd, lambda qkv, B, N, H, dh, scale: 4.0 * B * H * N * N * dh)
         ops.attention_bwd = self._timed("attention", ops.attention_bwd,
-                                        lambda qkv, out, dout, lse, B, N, H, dh, scale: 8.0 * B * H * N * N * dh)
+                                        lambda qkv, out, dout, lse, B, N, H, dh, scale, **kw: 8.0 * B * H * N * N * dh)
 
         # 3x3x3 and 1x1x1 convolutions (csrc/conv3d.hip): 2 x taps x voxels x Cin x Cout per forward / data-gradient / weight-gradient
         # launch, with the operand widths as launched (the zero channels of the 8-channel input operand are 1 % of the total)

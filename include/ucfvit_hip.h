@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 10
+#define UCFVIT_ABI_VERSION 11
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -166,6 +166,20 @@ int ucfvit_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int6
 int ucfvit_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                          float* delta_ws, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
                          void* stream);
+/* The same backward, also handing out what the qkv bias gradient needs (building_blocks.py:154 qkv = nn.Linear(dim, 3 dim, bias=qkv_bias): its
+ * bias gradient is dqkv summed over all B N token rows) so that dqkv is not read a second time for it:
+ *   colsum_partial fp32 [B][2][H][dh]: row b holds the column sums of dQ over batch element b's N tokens (from the fp32 gradients before they
+ *   are rounded), then H dh zeros for dK; the caller sums the B rows (ucfvit_reduce_rows) into the first two thirds of the bias gradient.
+ *   The K third of the bias gradient is identically zero — sum_key dS[q][key] = sum_key P (dP - delta) = delta - delta: a key bias shifts
+ *   every score of a row alike and the softmax does not see it (the reference's value there is rounding noise around 0) — and the V third
+ *   is the column sum of `dout` (sum_key P = 1), which the projection's data-gradient GEMM can produce in its epilogue
+ *   (ucfvit_gemm c_colsum_partial): neither needs this kernel.
+ * Only where the fused short-sequence kernel runs: ucfvit_attention_bwd_colsum_supported returns 1 (bf16, head dim 32 / 64, N <= 256),
+ * else 0 and ucfvit_attention_bwd_colsum fails with UCFVIT_ERR_UNSUPPORTED. */
+int ucfvit_attention_bwd_colsum_supported(int64_t B, int64_t N, int64_t H, int64_t dh, int dtype);
+int ucfvit_attention_bwd_colsum(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                float* delta_ws, float* colsum_partial, int64_t B, int64_t N, int64_t H, int64_t dh, float scale,
+                                int dtype, void* stream);
 
 /* Attention of a QUERY block against ANOTHER token block's keys / values: the building block of ring sequence parallelism (no reference
  * counterpart: the reference constructs seq_par_group and asserts seq_par_size == 1, training_scripts/train_masked_fsdp.py:220).

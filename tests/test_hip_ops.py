@@ -421,6 +421,35 @@ def test_attention_kernels_all_short_sequence_paths(N, dh):
     assert float((lse - ref_lse).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("N,dh,B,H", [(197, 64, 5, 3), (50, 64, 4, 2), (256, 32, 3, 2), (100, 32, 2, 4), (17, 64, 3, 1)])
+def test_attention_backward_hands_out_the_qkv_bias_column_sums(N, dh, B, H):
+    """ucfvit_attention_bwd_colsum: partial [B, 2 H dh] = dQ summed over each batch element's tokens (from the fp32 gradients before they are
+    rounded) and zeros for dK — against the fp32 sums of the bf16 dqkv the same call returns (tolerance: the rounding of N bf16 values per
+    column); the two identities the caller relies on for the other thirds hold on the returned gradient itself (column sums of dK = 0 and
+    of dV = column sums of dout, up to the rounding of the stored values); the gradient is bit-identical to the call without column sums
+    and a second call bit-identical (no atomics).  N > 256 and head dim 128 report 'not supported'."""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(N + dh + B)
+    D = H * dh
+    qkv = torch.randn(B * N, 3 * D, generator=gen).bfloat16().to(DEV)
+    do = torch.randn(B * N, D, generator=gen).bfloat16().to(DEV)
+    o, lse = ops.attention_fwd(qkv, B, N, H, dh, dh ** -0.5)
+    d0 = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
+    d1, part = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5, want_colsum=True)
+    d2, part2 = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5, want_colsum=True)
+    assert part is not None and part.shape == (B, 2 * D) and part.dtype == torch.float32
+    assert torch.equal(d0, d1) and torch.equal(d1, d2) and torch.equal(part, part2)
+    sums = d1.float().view(B, N, 3 * D).sum(1)                       # [B, 3 D] from the rounded gradient
+    scale = float(sums.abs().max())
+    assert float((part[:, :D] - sums[:, :D]).abs().max()) < 2e-2 * scale + 1e-3
+    assert float(part[:, D:].abs().max()) == 0.0
+    assert float(sums[:, D:2 * D].abs().max()) < 3e-2 * scale + 1e-3                                   # sum over keys of dK: rounding noise around 0
+    assert float((sums[:, 2 * D:] - do.float().view(B, N, D).sum(1)).abs().max()) < 3e-2 * scale + 1e-3  # sum over keys of dV = sum over queries of dO
+    assert ops.attention_bwd_colsum_supported(B, N, H, dh, torch.bfloat16)
+    assert not ops.attention_bwd_colsum_supported(B, 300, H, dh, torch.bfloat16) and not ops.attention_bwd_colsum_supported(B, N, H, 128, torch.bfloat16)
+    assert not ops.attention_bwd_colsum_supported(B, N, H, dh, torch.float32)
+
+
 # ---------------------------------------------------------------------------------------------- adaptive-patching front end
 @pytest.mark.parametrize("B,C,S,P", [(2, 3, 12, 64), (3, 1, 50, 256), (1, 4, 7, 27), (2, 3, 196, 256)])
 def test_seq_patches_is_an_exact_rearrangement(B, C, S, P):

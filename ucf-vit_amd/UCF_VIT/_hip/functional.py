@@ -313,10 +313,24 @@ def _attn_bwd(dy2, x2, saved, B, N, H, wqkv, wproj, p_qkvw, p_qkvb, p_projw, p_p
         g_projb = projb_done[0]
     else:
         g_projb = _bgrad(p_projb, dy2) if (p_projb is not None and needs[3]) else None
-    do = _dgrad(dy2, p_projw, wproj)
-    dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
+    want_b = p_qkvb is not None and needs[1]
+    if want_b and ops.attention_bwd_colsum_supported(B, N, H, dh, qkv.dtype):
+        # the qkv bias gradient without a second read of dqkv (include/ucfvit_hip.h, ucfvit_attention_bwd_colsum): Q third = the per-image
+        # column sums the backward kernel hands out, summed over the images; K third = 0 exactly; V third = the column sums of dO, taken in
+        # the epilogue of the GEMM that produces dO
+        Dl = H * dh
+        gb, acc = grad_target(p_qkvb)
+        if gb is None:
+            gb, acc = torch.empty(3 * Dl, dtype=torch.float32, device=dy2.device), False
+        do = _dgrad(dy2, p_projw, wproj, c_colsum=gb[2 * Dl:], c_colsum_accumulate=acc)
+        dqkv, part = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5, want_colsum=True)
+        ops.reduce_rows(part, gb[:2 * Dl], accumulate=acc)
+        g_qkvb = None if acc else gb
+    else:
+        do = _dgrad(dy2, p_projw, wproj)
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, dh, dh ** -0.5)
+        g_qkvb = _bgrad(p_qkvb, dqkv) if want_b else None
     g_qkvw = _wgrad(p_qkvw, dqkv, x2, wq) if needs[0] else None
-    g_qkvb = _bgrad(p_qkvb, dqkv) if (p_qkvb is not None and needs[1]) else None
     dx = _dgrad(dqkv, p_qkvw, wqkv)
     if tp:
         tp.all_reduce(dx)                                              # C2: entry gradient all-reduce

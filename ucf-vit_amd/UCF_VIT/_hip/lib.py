@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
 GEMM_SCHED_BYTES = 1024
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback
@@ -53,6 +53,8 @@ SIGNATURES = {
     "ucfvit_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _I, _P, _I, _P]),
     "ucfvit_attention_fwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
+    "ucfvit_attention_bwd_colsum_supported": (c_int, [_I64, _I64, _I64, _I64, _I]),
+    "ucfvit_attention_bwd_colsum": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_attention_cross_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "ucfvit_attention_cross_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P]),
     "ucfvit_attention_merge": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I, _P]),

@@ -261,14 +261,26 @@ def attention_fwd(qkv, B, N, H, dh, scale):
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, N, H, dh, scale):
+def attention_bwd_colsum_supported(B, N, H, dh, dtype):
+    return bool(_l.load().ucfvit_attention_bwd_colsum_supported(B, N, H, dh, _DT[dtype]))
+
+
+def attention_bwd(qkv, out, dout, lse, B, N, H, dh, scale, want_colsum=False):
+    """-> dqkv, or (dqkv, partial) with want_colsum: partial fp32 [B, 2 H dh] = the column sums of dQ over each batch element's tokens and
+    zeros for dK (include/ucfvit_hip.h: the K third of the qkv bias gradient is identically 0, the V third is the column sum of dout), or
+    None where the shape runs the streaming kernels (the caller sums dqkv itself)"""
     L = _l.load()
     _chk(dout, "attention_bwd.dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    if want_colsum and L.ucfvit_attention_bwd_colsum_supported(B, N, H, dh, dt(qkv)):
+        part = torch.empty((B, 2 * H * dh), dtype=torch.float32, device=qkv.device)
+        _l.check(L.ucfvit_attention_bwd_colsum(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                                               part.data_ptr(), B, N, H, dh, scale, dt(qkv), _stream()), "ucfvit_attention_bwd_colsum")
+        return dqkv, part
     _l.check(L.ucfvit_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
                                     B, N, H, dh, scale, dt(qkv), _stream()), "ucfvit_attention_bwd")
-    return dqkv
+    return (dqkv, None) if want_colsum else dqkv
 
 
 def attention_cross_fwd(q, k, v, B, Nq, Nk, H, dh, scale):

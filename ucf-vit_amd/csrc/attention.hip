@@ -21,8 +21,9 @@
 // attention_short.hip: whole-sequence-in-LDS kernels for N <= 256 (return 1 = handled, 0 = not applicable, <0 = error)
 int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype,
                                hipStream_t s);
-int ucfvit_attention_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H,
-                               int64_t dh, float scale, int dtype, hipStream_t s);
+int ucfvit_attention_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* cs_partial, int64_t B, int64_t N,
+                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s);
+int ucfvit_attention_fused_bwd_applies(int64_t B, int64_t N, int64_t H, int64_t dh, int dtype);
 
 
 namespace {
@@ -762,13 +763,18 @@ int attn_fwd_launch(const void* qkv, void* out, float* lse, int64_t B, int64_t N
 }
 
 template <typename T, int DH>
-int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int64_t B, int64_t N,
-                    int64_t H, float scale, hipStream_t s) {
+int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, float* cs_partial, int64_t B,
+                    int64_t N, int64_t H, float scale, hipStream_t s) {
     // the FUSED backward (one launch, operands read once, delta = rowsum(dO o O) taken inside) is the default where it applies
     {
-        const int rc = ucfvit_attention_fused_bwd(qkv, out, dout, lse, dqkv, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
+        const int rc = ucfvit_attention_fused_bwd(qkv, out, dout, lse, dqkv, cs_partial, B, N, H, DH, scale, sizeof(T) == 2 ? UCFVIT_BF16 : UCFVIT_F32, s);
         if (rc == 1) return UCFVIT_OK;
         if (rc < 0) return rc;
+    }
+    if (cs_partial) {
+        ucfvit_set_error("ucfvit_attention_bwd_colsum: this shape runs the streaming kernels, which produce no column sums (ask "
+                         "ucfvit_attention_bwd_colsum_supported first)");
+        return UCFVIT_ERR_UNSUPPORTED;
     }
     AttnArgs<T> a = self_args<T>(qkv, N, H, DH);
     const int64_t D = H * DH;
@@ -926,7 +932,21 @@ extern "C" int ucfvit_attention_bwd(const void* qkv, const void* out, const void
     if (rc) return rc;
     UCF_CHECK_ARG(ucf_is_aligned16(qkv) && ucf_is_aligned16(out) && ucf_is_aligned16(dout) && ucf_is_aligned16(dqkv),
                   "ucfvit_attention_bwd: pointers must be 16-byte aligned");
-    ATTN_DISPATCH(attn_bwd_launch, qkv, out, dout, lse, dqkv, delta_ws, B, N, H, scale, (hipStream_t)stream);
+    ATTN_DISPATCH(attn_bwd_launch, qkv, out, dout, lse, dqkv, delta_ws, (float*)nullptr, B, N, H, scale, (hipStream_t)stream);
+}
+
+extern "C" int ucfvit_attention_bwd_colsum_supported(int64_t B, int64_t N, int64_t H, int64_t dh, int dtype) {
+    return ucfvit_attention_fused_bwd_applies(B, N, H, dh, dtype);
+}
+
+extern "C" int ucfvit_attention_bwd_colsum(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
+                                           float* colsum_partial, int64_t B, int64_t N, int64_t H, int64_t dh, float scale, int dtype, void* stream) {
+    UCF_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws && colsum_partial, "ucfvit_attention_bwd_colsum: null pointer");
+    int rc = check_attn_args("ucfvit_attention_bwd_colsum", B, N, H, dh, dtype);
+    if (rc) return rc;
+    UCF_CHECK_ARG(ucf_is_aligned16(qkv) && ucf_is_aligned16(out) && ucf_is_aligned16(dout) && ucf_is_aligned16(dqkv),
+                  "ucfvit_attention_bwd_colsum: pointers must be 16-byte aligned");
+    ATTN_DISPATCH(attn_bwd_launch, qkv, out, dout, lse, dqkv, delta_ws, colsum_partial, B, N, H, scale, (hipStream_t)stream);
 }
 
 extern "C" int ucfvit_attention_cross_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t Nq, int64_t Nk,

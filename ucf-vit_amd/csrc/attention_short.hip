@@ -400,11 +400,36 @@ __device__ __forceinline__ void ag_store4(__amdgpu_buffer_rsrc_t r, int byte_off
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), r, byte_off, 0, 0);
 }
 
+// sum over the 16 lanes of a DPP row (= one lane group g), in every lane of the row: four v_add_f32 with DPP operands (quad swaps, then the
+// half-row and the row mirrored), no LDS crossbar traffic (hipcc turns __shfl_xor by 4 and 8 into ds_bpermute_b32)
+__device__ __forceinline__ float ag_row16_sum(float t) {
+#define AG_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+    t += AG_DPP(t, 0xB1);        // quad_perm [1, 0, 3, 2]
+    t += AG_DPP(t, 0x4E);        // quad_perm [2, 3, 0, 1]
+    t += AG_DPP(t, 0x141);       // row_half_mirror
+    t += AG_DPP(t, 0x140);       // row_mirror
+#undef AG_DPP
+    return t;
+}
+
+// column sums of the dQ tiles for the qkv bias gradient: v[d][r] holds, for head-dim index 16 d + 4 g + r, this lane's column (one
+// query or key); the 16 lanes of a group are summed and lane li = 0 adds the group's total into the wave's own LDS row (no atomics: index
+// 16 d + 4 g + r belongs to exactly one lane of the wave, passes follow each other)
+template <int NDB> __device__ __forceinline__ void ag_colsum_add(float (&v)[NDB][4], float* __restrict__ row, int g, int li, float mul) {
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = ag_row16_sum(v[d][r]);
+            if (li == 0) row[d * 16 + 4 * g + r] += t * mul;
+        }
+}
+
 // phase A for the query blocks blk0 .. blk0 + NJ - 1: K in slot 0, V in slot 1.  -delta is the initial value of the dP accumulator, so
 // dS = P o (dP - delta) is one multiply.
 template <int NJ, int DH, int NB, bool EXACT>
 __device__ __forceinline__ void ag_dq_pass(const AgCtx<DH, NB, EXACT>& cx, int blk0, const AgOpsA<NJ, DH / 32>& o, float* __restrict__ ldsDeltaW,
-                                           __amdgpu_buffer_rsrc_t rDQ, int rs_bytes) {
+                                           __amdgpu_buffer_rsrc_t rDQ, int rs_bytes, float* __restrict__ cs_row) {
     typedef bf16 T;
     typedef AgCtx<DH, NB, EXACT> C;
     constexpr int RB = C::RB, NCH = C::NCH, NDB = C::NDB, NRC = C::NRC;
@@ -480,6 +505,18 @@ __device__ __forceinline__ void ag_dq_pass(const AgCtx<DH, NB, EXACT>& cx, int b
         const int q = (blk0 + j) * 16 + li;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) ag_store4(rDQ, q * rs_bytes + d * 32 + 8 * g, dq[j][d], cx.scale);       // rows >= N: dropped by the range check
+    }
+    if (cs_row) {                                      // padding queries carry dQ = 0 (their P is 0)
+        float v[NDB][4];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[d][r] = dq[0][d][r];
+#pragma unroll
+                for (int j = 1; j < NJ; ++j) v[d][r] += dq[j][d][r];
+            }
+        ag_colsum_add<NDB>(v, cs_row, g, li, cx.scale);
     }
 }
 
@@ -570,7 +607,8 @@ __device__ __forceinline__ void ag_dkv_pass(const AgCtx<DH, NB, EXACT>& cx, int 
 template <int DH, int NB, bool EXACT>
 __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                  const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
+                                                                 bf16* __restrict__ dqkv, float* __restrict__ cs_partial, int N, int H, float scale,
+                                                                 float scale_log2e) {
     typedef bf16 T;
     constexpr int RB = DH * 2, NCH = DH / 32, NRC = (NB + 1) / 2, ROWS = NRC * 32, IMG = ROWS * RB, NJ = NB > 8 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -578,6 +616,7 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
     char* slot1 = smem + IMG;           // V, then dO
     float* ldsLse = reinterpret_cast<float*>(smem + 2 * IMG);   // [ROWS]
     float* ldsDelta = ldsLse + ROWS;
+    float* ldsCs = ldsDelta + ROWS;                              // [4 waves][DH] column sums of dQ (cs_partial only)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % H;
@@ -609,6 +648,9 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
         ldsLse[i] = i < N ? lse_bh[i] : INFINITY;    // +inf -> P = 0 for padding queries
         ldsDelta[i] = 0.f;                           // phase A fills the blocks that exist (with -delta)
     }
+    if (cs_partial)
+        for (int i = tid; i < AG_WAVES * DH; i += AG_THREADS) ldsCs[i] = 0.f;
+    float* cs_row = cs_partial ? ldsCs + wave * DH : nullptr;
     AgStage<ROWS, DH> sq, sdo;                           // phase B's images travel while phase A computes
     ag_fetch<ROWS, DH>(sq, rQ, 0, rs_bytes, tid);
     ag_fetch<ROWS, DH>(sdo, rDO, 0, d_bytes, tid);
@@ -633,9 +675,9 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
     cx.sl2 = scale_log2e;
 
     // ---------------- phase A: dQ (K in slot 0, V in slot 1) ----------------------------------------------------------
-    ag_dq_pass<NJ>(cx, wave * NJ, oa, ldsDelta, rDQ, rs_bytes);
+    ag_dq_pass<NJ>(cx, wave * NJ, oa, ldsDelta, rDQ, rs_bytes, cs_row);
     AG_STAMP_HERE(3);
-    if (wave * NJ + STEP < nqb) ag_dq_pass<NJ>(cx, wave * NJ + STEP, oa2, ldsDelta, rDQ, rs_bytes);
+    if (wave * NJ + STEP < nqb) ag_dq_pass<NJ>(cx, wave * NJ + STEP, oa2, ldsDelta, rDQ, rs_bytes, cs_row);
     AG_STAMP_HERE(4);
     // the first phase-B pass's K / V blocks come out of the images before Q / dO replace them (reverse wave order in phase B)
     const int bw = AG_WAVES - 1 - wave;
@@ -661,6 +703,15 @@ __global__ __launch_bounds__(AG_THREADS, 2) void attn_g_bwd_kernel(const bf16* _
     AG_STAMP_HERE(11);
     if (bw * NJ + STEP < nqb) ag_dkv_pass<NJ>(cx, bw * NJ + STEP, ob2, rDQ, rs_bytes, d_bytes);
     AG_STAMP_HERE(16);
+    if (cs_partial) {
+        // this (batch, head)'s column sums of dQ over its tokens, the four waves added in a fixed order: row b of [B][2][H][DH].  (Phase A is
+        // long finished; the barrier between the phases ordered the waves' LDS rows.)
+        for (int i = tid; i < 2 * DH; i += AG_THREADS) {
+            const int d = i % DH;
+            const float t = (ldsCs[d] + ldsCs[DH + d]) + (ldsCs[2 * DH + d] + ldsCs[3 * DH + d]);
+            cs_partial[b * (2 * D) + (i / DH) * D + h * DH + d] = i < DH ? t : 0.f;      // [B][2][H][DH]: dQ's sums, then dK's (identically 0)
+        }
+    }
 }
 
 
@@ -785,19 +836,19 @@ int launch_s3_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t N, 
 }
 
 template <int DH, int NB>
-int launch_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H, float scale,
-                     hipStream_t s) {
+int launch_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* cs_partial, int64_t B, int64_t N, int64_t H,
+                     float scale, hipStream_t s) {
     constexpr int ROWS = ((NB + 1) / 2) * 32;
-    constexpr size_t smem = 2 * (size_t)ROWS * (DH * 2) + 2 * ROWS * sizeof(float);
+    constexpr size_t smem = 2 * (size_t)ROWS * (DH * 2) + 2 * ROWS * sizeof(float) + AG_WAVES * DH * sizeof(float);
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 grid((unsigned)(B * H)), block(AG_THREADS);
     if ((N + 15) / 16 == NB) {
         if (int rc = big_lds(attn_g_bwd_kernel<DH, NB, true>, smem)) return rc;
-        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, true>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, cs_partial, (int)N,
                            (int)H, scale, sl2);
     } else {
         if (int rc = big_lds(attn_g_bwd_kernel<DH, NB, false>, smem)) return rc;
-        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N,
+        hipLaunchKernelGGL((attn_g_bwd_kernel<DH, NB, false>), grid, block, smem, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, cs_partial, (int)N,
                            (int)H, scale, sl2);
     }
     UCF_LAUNCH_CHECK("ucfvit_attention_bwd(fused)");
@@ -833,17 +884,23 @@ int ucfvit_attention_short_fwd(const void* qkv, void* out, float* lse, int64_t B
     AS_PICK(launch_fwd, bf16, 32, qkv, out, lse, B, N, H, scale, s);
 }
 
-// fused backward (bf16, head dim 64 or 32, N <= 256; needs no delta workspace): 1 = handled, 0 = not applicable, <0 = error
-int ucfvit_attention_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t N, int64_t H,
-                               int64_t dh, float scale, int dtype, hipStream_t s) {
-    if (dtype != UCFVIT_BF16 || N > 256 || (dh != 64 && dh != 32) || B * H >= (1ll << 31)) return 0;
+int ucfvit_attention_fused_bwd_applies(int64_t B, int64_t N, int64_t H, int64_t dh, int dtype) {
+    return (dtype == UCFVIT_BF16 && N <= 256 && (dh == 64 || dh == 32) && B * H < (1ll << 31)) ? 1 : 0;
+}
+
+// fused backward (bf16, head dim 64 or 32, N <= 256; needs no delta workspace): 1 = handled, 0 = not applicable, <0 = error.
+// cs_partial (may be null): fp32 [B][2][H][dh], row b = the column sums of dQ over batch element b's tokens, then zeros for dK (see
+// ucfvit_attention_bwd_colsum)
+int ucfvit_attention_fused_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* cs_partial, int64_t B, int64_t N,
+                               int64_t H, int64_t dh, float scale, int dtype, hipStream_t s) {
+    if (!ucfvit_attention_fused_bwd_applies(B, N, H, dh, dtype)) return 0;
     const int nb = (int)((N + 15) / 16);
     int rc;
 #define AF_BWD(DH_)                                                                                       \
-    (nb <= 4 ? launch_fused_bwd<DH_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, s)                     \
-             : nb <= 8 ? launch_fused_bwd<DH_, 8>(qkv, out, dout, lse, dqkv, B, N, H, scale, s)           \
-                       : nb <= 13 ? launch_fused_bwd<DH_, 13>(qkv, out, dout, lse, dqkv, B, N, H, scale, s) \
-                                  : launch_fused_bwd<DH_, 16>(qkv, out, dout, lse, dqkv, B, N, H, scale, s))
+    (nb <= 4 ? launch_fused_bwd<DH_, 4>(qkv, out, dout, lse, dqkv, cs_partial, B, N, H, scale, s)                     \
+             : nb <= 8 ? launch_fused_bwd<DH_, 8>(qkv, out, dout, lse, dqkv, cs_partial, B, N, H, scale, s)           \
+                       : nb <= 13 ? launch_fused_bwd<DH_, 13>(qkv, out, dout, lse, dqkv, cs_partial, B, N, H, scale, s) \
+                                  : launch_fused_bwd<DH_, 16>(qkv, out, dout, lse, dqkv, cs_partial, B, N, H, scale, s))
     rc = dh == 64 ? AF_BWD(64) : AF_BWD(32);
 #undef AF_BWD
     return rc == UCFVIT_OK ? 1 : rc;
