@@ -450,6 +450,26 @@ def test_attention_backward_hands_out_the_qkv_bias_column_sums(N, dh, B, H):
     assert not ops.attention_bwd_colsum_supported(B, N, H, dh, torch.float32)
 
 
+@pytest.mark.parametrize("M,N,K", [(665 * 197, 1024, 1024), (4096, 768, 768), (1000, 512, 256), (300, 64, 128)])
+def test_plain_data_gradient_column_sums_from_the_epilogue(M, N, K):
+    """dx = dy W with c_colsum: the column sums of dx (the V third of the qkv bias gradient when dx = dO) — from the plain epilogue of the
+    256 x 256 ping-pong kernel where it runs (the first three shapes), by a separate pass otherwise; against the fp32 sum of the bf16 dx
+    returned; the product equals the call without column sums (bit for bit below K = 1024; at K >= 1024 that call runs the staggered
+    kernel, whose second wave group adds its K-tiles in rotated order: last-bit differences); accumulate adds"""
+    from UCF_VIT._hip import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, K, generator=gen).bfloat16().to(DEV)
+    wT = (torch.randn(N, K, generator=gen) * 0.05).bfloat16().to(DEV)          # dx[M, N] = dy[M, K] . wT[N, K]^T
+    dx0 = ops.linear_dgrad_t(dy, wT)
+    cs = torch.full((N,), 7.0, dtype=torch.float32, device=DEV)
+    dx1 = ops.linear_dgrad_t(dy, wT, c_colsum=cs)
+    assert torch.equal(dx0, dx1) if K < 1024 else rel_err(dx1.float(), dx0.float()) < 4e-3
+    want = dx1.float().sum(0)
+    assert rel_err(cs, want) < 5e-3
+    ops.linear_dgrad_t(dy, wT, c_colsum=cs, c_colsum_accumulate=True)
+    assert rel_err(cs, 2 * want) < 5e-3
+
+
 # ---------------------------------------------------------------------------------------------- adaptive-patching front end
 @pytest.mark.parametrize("B,C,S,P", [(2, 3, 12, 64), (3, 1, 50, 256), (1, 4, 7, 27), (2, 3, 196, 256)])
 def test_seq_patches_is_an_exact_rearrangement(B, C, S, P):

@@ -1174,8 +1174,10 @@ int launch3(const ucfvit_gemm_desc* d, const Plan2& p, Epi2 ep, hipStream_t s) {
             const int rs = ucfvit_gemm_stagger_try(d, s);
             if (rs == 1) return UCFVIT_OK;
             if (rs < 0) return rs;
-            if (ep.act == UCFVIT_ACT_NONE && !ep.residual && !ep.aux_out)
+            if (ep.act == UCFVIT_ACT_NONE && !ep.residual && !ep.aux_out) {
+                if (ep.cs_partial) return launch3g<LA, LB, OutT, EPI_PLAIN, true, 1>(gt, K_, ep, 1, p.k_per_split, s);
                 return launch3g<LA, LB, OutT, EPI_PLAIN, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
+            }
             if (ep.act == UCFVIT_ACT_NONE && ep.residual && !ep.aux_out)
                 return launch3g<LA, LB, OutT, EPI_RESIDUAL, false, 1>(gt, K_, ep, 1, p.k_per_split, s);
             if (ep.act == UCFVIT_ACT_GELU && !ep.residual)
@@ -1230,15 +1232,17 @@ static bool v2_operands_ok(const ucfvit_gemm_desc* d) {
     return ok;
 }
 
-// the output column sums (desc->c_colsum_partial) exist in the specialised MUL_AUX epilogue of the 256x256 ping-pong kernel: the
-// data-gradient GEMM through the activation (C = dh of the MLP), two 128-row blocks per output tile row
+// the output column sums (desc->c_colsum_partial) exist in the specialised MUL_AUX and plain epilogues of the 256x256 ping-pong kernel: the
+// data-gradient GEMM through the activation (C = dh of the MLP) and the plain data gradients (C = dO of the attention projection: the V
+// third of the qkv bias gradient), two 128-row blocks per output tile row
 static int64_t colsum_rows_for(const ucfvit_gemm_desc* d) {
     Plan2 p;
     if (!d || !plan2(d, &p) || !v2_operands_ok(d)) return 0;
     const int64_t a_bytes = d->M * d->lda * 2, b_bytes = d->N * d->ldb * 2;
     const bool path = p.big && p.splits == 1 && pp_enabled() && !generic_epilogue_only() && a_bytes < (1ll << 32) && b_bytes < (1ll << 32) &&
                       d->a_layout == UCFVIT_LAYOUT_KC && d->b_layout == UCFVIT_LAYOUT_KC && d->out_dtype == UCFVIT_BF16 && !d->accumulate &&
-                      d->N >= 8 && d->act == UCFVIT_ACT_MUL_AUX && !d->residual && !d->aux_out;
+                      d->N >= 8 && !d->residual && !d->aux_out &&
+                      (d->act == UCFVIT_ACT_MUL_AUX || (d->act == UCFVIT_ACT_NONE && !d->aux_in));
     return path ? 2 * ((d->M + 255) / 256) : 0;
 }
 
