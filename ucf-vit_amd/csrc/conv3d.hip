@@ -197,9 +197,33 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
     const int ix = t % g.tx, b = t / g.tx;
     const int x0 = ix * TX, y0 = iy * TY;
     const int co0 = blockIdx.y * CB;
-    for (int p = tid; p < G::NTS * CB * 4; p += CT) {
-        const int piece = p & 3, row = (p >> 2) % CB, ts = (p >> 2) / CB;
-        *reinterpret_cast<u32x4*>(wl + p * 16) = *reinterpret_cast<const u32x4*>(wp + ((int64_t)ts * g.Cout + co0 + row) * 32 + piece * 8);
+    // SHARE (3x3x3, 16 input channels): a wave's RPW voxel rows are consecutive in y at one x, and the B fragment of halo row hy is the
+    // same for (output row yl, tap dy) whenever yl + dy = hy — read once, it feeds up to three MFMAs (the kernel was LDS-read bound: one
+    // ds_read_b128 per MFMA at 16 output channels).  For that the taps folded into one 32-wide step must not mix dy: the step types are the
+    // (dx, dz) pairs {00,01} {10,11} {20,21} {02,12} {22,-} for each dy (15 steps instead of 14), re-assembled from the packed weights while
+    // they are staged.
+    // (Measured at 512 x 512 x 128, B = 2: the 16 -> 16 full-resolution layer 1567 -> 1440 us, 16 -> 32 3154 -> 3022; with 32 input channels
+    // — two MFMAs per fragment already — 544 -> 569 us, so those keep one fragment per (row, tap).)
+    constexpr bool SHARE = KS == 3 && CPC == 16 && RPW <= TY && TY % RPW == 0;
+    constexpr int NST = CPC == 16 ? 5 : 9;              // step types (dy-free), SHARE only
+    if constexpr (SHARE && CPC == 16) {
+        for (int p = tid; p < NST * 3 * CB * 4; p += CT) {
+            const int piece = p & 3, row = (p >> 2) % CB, slot = (p >> 2) / CB, st = slot / 3, dy = slot % 3, second = piece >> 1;
+            // (dx, dz) of the two taps of step type st: 0x(dx << 2 | dz) per half
+            const int code = second ? ((0x1 << 0) | (0x5 << 4) | (0x9 << 8) | (0x6 << 12) | (0xF << 16)) : ((0x0 << 0) | (0x4 << 4) | (0x8 << 8) | (0x2 << 12) | (0xA << 16));
+            const int dxdz = (code >> (4 * st)) & 0xF;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (dxdz != 0xF) {
+                const int tap = 9 * (dxdz >> 2) + 3 * dy + (dxdz & 3);
+                v = *reinterpret_cast<const u32x4*>(wp + ((int64_t)(tap >> 1) * g.Cout + co0 + row) * 32 + (tap & 1) * 16 + (piece & 1) * 8);
+            }
+            *reinterpret_cast<u32x4*>(wl + p * 16) = v;
+        }
+    } else {
+        for (int p = tid; p < G::NTS * CB * 4; p += CT) {
+            const int piece = p & 3, row = (p >> 2) % CB, ts = (p >> 2) / CB;
+            *reinterpret_cast<u32x4*>(wl + p * 16) = *reinterpret_cast<const u32x4*>(wp + ((int64_t)ts * g.Cout + co0 + row) * 32 + piece * 8);
+        }
     }
     // this thread's pieces of a halo: fixed (hx, hy, hz, piece) for every z tile
     int hoff[NPT], hxy[NPT], hzz[NPT];
@@ -262,6 +286,51 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SHARE) {
+            const int xl = (wave * RPW) / TY, yl0 = (wave * RPW) % TY;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                frag_t a[3][NB];
+                int dx, dz, chb;
+                if (CPC == 32) {
+                    dx = st / 3;
+                    dz = st % 3;
+                    chb = lg * 16;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            a[dy][nb] = *reinterpret_cast<const frag_t*>(wl + (((9 * dx + 3 * dy + dz) * CB + nb * 16 + li) * 64 + lg * 16));
+                } else {
+                    // this lane's half of the step: lanes lg 0, 1 the first tap, lg 2, 3 the second (the padding half reads the first tap's voxels
+                    // against zero weights)
+                    const int second = lg >> 1;
+                    const int dxdz = st == 0 ? (second ? 0x1 : 0x0) : st == 1 ? (second ? 0x5 : 0x4) : st == 2 ? (second ? 0x9 : 0x8)
+                                   : st == 3 ? (second ? 0x6 : 0x2) : 0xA;
+                    dx = dxdz >> 2;
+                    dz = dxdz & 3;
+                    chb = (lg & 1) * 16;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            a[dy][nb] = *reinterpret_cast<const frag_t*>(wl + (((st * 3 + dy) * CB + nb * 16 + li) * 64 + lg * 16));
+                }
+                const int boff = (((dx + xl) * HY + yl0) * HZ + dz + li) * G::VS + chb;
+#pragma unroll
+                for (int j = 0; j < RPW + 2; ++j) {
+                    const frag_t bf = *reinterpret_cast<const frag_t*>(halo + boff + j * HZ * G::VS);
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = j - dy;
+                        if (r >= 0 && r < RPW) {
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) acc[r][nb] = mma(a[dy][nb], bf, acc[r][nb]);
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int ts = 0; ts < G::NTS; ++ts) {
             frag_t a[NB];
@@ -288,6 +357,7 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[r][nb] = mma(a[nb], bf, acc[r][nb]);
             }
+        }
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
@@ -735,7 +805,8 @@ int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, 
     const int64_t cols = (int64_t)g.B * g.tx * g.ty;
     UCF_CHECK_ARG(cols < (1ll << 31) && g.Cout / (16 * NB) < 65536, "ucfvit_conv3d_fwd: grid too large");
     g.tiles = (int)cols;
-    constexpr int SMEM = (TX + 2 * G::PAD) * (TY + 2 * G::PAD) * (16 + 2 * G::PAD) * G::VS + G::NTS * 16 * NB * 64;
+    constexpr int WSLOTS = (KS == 3 && CPC == 16) ? 15 : G::NTS;            // the dy-free step arrangement of conv_fwd_strip_kernel (SHARE)
+    constexpr int SMEM = (TX + 2 * G::PAD) * (TY + 2 * G::PAD) * (16 + 2 * G::PAD) * G::VS + WSLOTS * 16 * NB * 64;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
