@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UCFVIT_ABI_VERSION 11
+#define UCFVIT_ABI_VERSION 12
 
 #define UCFVIT_OK 0
 #define UCFVIT_ERR_INVALID_ARGUMENT (-1)
@@ -419,9 +419,11 @@ int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void* x, const 
  *   fp32 (out_dtype).  Cin in {8, 16, 32 k}, Cout = 16 k = the rows of w_packed; cout_store <= Cout channels are written with row stride
  *   ldy (a 4-class head writes [V][4] from a 16-row weight block); bias fp32 [Cout] or NULL; accumulate: y += result (the second of two
  *   data gradients that flow into the same input, e.g. a residual block's 3x3x3 and 1x1x1 branches).
- *   stats_partial (may be NULL): the instance-norm statistics of the OUTPUT as a by-product — per-channel sum and sum of squares of the
- *   rounded outputs, [B][rows][2][Cout] fp32 with rows = ucfvit_conv3d_fwd_stats_rows(...) (0: the kernel serving this shape has no such
- *   epilogue); ucfvit_instnorm_cl_stats_fold turns them into mean / rstd, which saves the statistics pass over the output.
+ *   stats_partial (may be NULL): the instance-norm statistics of the OUTPUT as a by-product — per channel the count, the mean and
+ *   M2 = sum (q - mean)^2 of the rounded outputs each wave stored (accumulated relative to a per-wave shift, so a channel whose |mean| is far
+ *   larger than its spread keeps its variance bits), [B][rows][3][Cout] fp32 with rows = ucfvit_conv3d_fwd_stats_rows(...) (0: the kernel
+ *   serving this shape has no such epilogue); ucfvit_instnorm_cl_stats_fold combines the rows (parallel-variance formula, double) into
+ *   mean / rstd, which saves the statistics pass over the output.
  *   w_packed (bf16) holds the weights per 32-wide contraction step: with CPC = min(Cin, 32), TPS = 32 / CPC taps per step and
  *   NTS = ceil(ksize^3 / TPS) steps per channel chunk, w_packed[cc][ts][co][kk] = w[co][cc CPC + kk % CPC][tap] for tap = ts TPS + kk / CPC
  *   (zero when tap >= ksize^3); tap = (dx 3 + dy) 3 + dz.  The data gradient is the same call on dy with the flipped, transposed weights.

@@ -148,6 +148,33 @@ torch.save(out, sys.argv[1])
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,ks,shape", [(16, 16, 1, (2, 32, 128, 40)), (32, 32, 1, (2, 32, 128, 24)), (16, 16, 3, (2, 32, 128, 48)), (64, 32, 3, (2, 32, 128, 32))])
+def test_epilogue_statistics_keep_their_variance_when_the_mean_is_large(cin, cout, ks, shape):
+    """instance-norm statistics from the convolution epilogue (count / mean / M2 per wave, accumulated relative to a shift, combined with the
+    parallel-variance formula) on outputs whose |mean| is hundreds of standard deviations — the case E[q^2] - mean^2 in fp32 cannot hold
+    (round-2 advisor finding): against the double-precision statistics of the stored output and against the stand-alone statistics kernel.
+    Pointwise layers: outputs 50 +- a few bf16 steps; 3x3x3: the interior at 50, the zero-padded faces lower (large spread, same check)."""
+    from UCF_VIT._hip import conv, ops
+    g = torch.Generator().manual_seed(cin + cout + ks)
+    B, X, Y, Z = shape
+    x = (1.0 + 0.01 * torch.randn(B, X, Y, Z, cin, generator=g)).bfloat16().cuda()
+    w = torch.full((cout, cin, ks, ks, ks), 50.0 / (cin * ks ** 3)) * (1.0 + 0.002 * torch.randn(cout, 1, 1, 1, 1, generator=g))
+    wp = conv.pack_conv_weight(w).cuda()
+    from UCF_VIT._hip import lib
+    assert lib.load().ucfvit_conv3d_fwd_stats_rows(B, X, Y, Z, cin, cout, ks, 0) > 0          # these shapes DO take the epilogue path
+    y, mean, rstd = ops.conv3d_fwd(x, wp, cout, ksize=ks, stats_eps=1e-5)
+    ref = y.double().reshape(B, -1, cout)
+    m_ref, v_ref = ref.mean(1), ref.var(1, unbiased=False)
+    r_ref = (v_ref + 1e-5).rsqrt()
+    if ks == 1:
+        assert float((m_ref.abs() / v_ref.sqrt()).min()) > 100            # the pathological regime
+    assert float((mean.double() - m_ref).abs().max()) < 1e-4 * float(m_ref.abs().max())
+    assert float((rstd.double() / r_ref - 1).abs().max()) < 1e-3
+    m2, r2 = ops.instnorm_cl_stats(y, 1e-5)
+    assert float((rstd / r2 - 1).abs().max()) < 1e-3 and float((mean - m2).abs().max()) < 1e-4 * float(m_ref.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pad_rows8_dense_rows_and_channel_slices(dtype):
     """narrow channels-last rows -> bf16 rows of 8 (ucfvit_pad_rows8): dense [.., 4], a 4-channel slice of a 16-channel buffer, the permuted

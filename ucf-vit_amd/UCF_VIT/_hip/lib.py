@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 LAYOUT_KC, LAYOUT_KS = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
 GEMM_SCHED_BYTES = 1024
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # .../ucf-vit_amd
 # UCFVIT_HIP_LIB: an alternative build of the same library (A/B measurements of kernel variants); never a non-HIP fallback

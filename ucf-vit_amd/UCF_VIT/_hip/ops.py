@@ -711,8 +711,8 @@ def conv3d_fwd(x, w_packed, cout, ksize=3, bias=None, cout_store=None, out_dtype
             raise ValueError("conv3d: statistics need a dense bf16 output without accumulation")
         rows = L.ucfvit_conv3d_fwd_stats_rows(B, X, Y, Z, cin, cout, ksize, 0 if bias is None else 1)
         if rows:
-            buf = workspace((B * rows * 2 * cout + B * 256 * 2 * cout) * 4, x.device)       # partials, then the first fold stage's scratch
-            part, fold_ws = buf, buf[B * rows * 2 * cout:]
+            buf = workspace((B * rows * 3 * cout + B * 256 * 3 * cout) * 4, x.device)       # partial rows (count, mean, M2), then the first fold stage's scratch
+            part, fold_ws = buf, buf[B * rows * 3 * cout:]
     _l.check(L.ucfvit_conv3d_fwd(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), B, X, Y, Z, cin, cout, ksize, cs, cs, dt(y),
                                  0 if accumulate_into is None else 1, _p(part), _stream()), "ucfvit_conv3d_fwd")
     if stats_eps is None:

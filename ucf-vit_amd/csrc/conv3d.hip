@@ -80,6 +80,24 @@ __device__ __forceinline__ void decode_tile(const ConvGeo& g, int t, int& b, int
     b = t / g.tx;
 }
 
+// One partial row of the statistics epilogue ([column * 4 + wave][3][Cout] fp32): per channel the COUNT of outputs this wave stored, their
+// MEAN and M2 = sum (q - mean)^2.  The sums are accumulated relative to a per-(wave, channel) shift — the wave's first computed output of
+// that channel — so a channel whose |mean| is far larger than its spread keeps its variance bits (E[q^2] - mean^2 in fp32 does not);
+// ucfvit_instnorm_cl_stats_fold combines the rows with the parallel-variance formula in double.
+__device__ __forceinline__ void stats_row_write(float* __restrict__ sp, int Cout, int c, float s1, float s2, float shift, float n, bool writer) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {                          // over the 16 voxel lanes of a channel group
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (writer) {
+        const float inv = n > 0.f ? 1.f / n : 0.f;
+        sp[c] = n;
+        sp[Cout + c] = n > 0.f ? shift + s1 * inv : 0.f;
+        sp[2 * Cout + c] = fmaxf(s2 - s1 * s1 * inv, 0.f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- forward / data gradient
 template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
 __global__ __launch_bounds__(CT) void conv_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias,
@@ -254,11 +272,12 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
     const bool vec_ok = (g.ldy & 3) == 0;
     // stats (optional): per-channel sum and sum of squares of the ROUNDED outputs of this column, per wave — the instance-norm statistics of the
     // layer's output without a pass over it ([column * 4 + wave][2][Cout] partials, folded by ucfvit_instnorm_cl_stats_fold)
-    float st1[NB][4], st2[NB][4];
+    float st1[NB][4], st2[NB][4], shf[NB][4];
+    float cnt = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) st1[nb][e] = st2[nb][e] = 0.f;
+        for (int e = 0; e < 4; ++e) st1[nb][e] = st2[nb][e] = shf[nb][e] = 0.f;
     for (int iz = 0; iz < g.tz; ++iz) {
         const int z0 = iz * 16;
 #pragma unroll
@@ -359,10 +378,22 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
             }
         }
         }
+        if (stats && iz == 0) {
+            // the shift of the statistics: this wave's first computed output per channel (lane li = 0 of each channel group), rounded like a
+            // stored one; any finite value near the data serves (a voxel outside the volume computes from the zero padding)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = acc[0][nb][e] + (bias ? bias[co0 + nb * 16 + lg * 4 + e] : 0.f);
+                    shf[nb][e] = __shfl(to_f32<OutT>(from_f32<OutT>(v0)), lane & 48, 64);
+                }
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
             if (gx < g.X && gy < g.Y && gz < g.Z) {
+                if (stats) cnt += 1.f;
                 OutT* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.ldy;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -382,7 +413,7 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
                         if (stats) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float q = o.get(e);
+                                const float q = o.get(e) - shf[nb][e];
                                 st1[nb][e] += q;
                                 st2[nb][e] = fmaf(q, q, st2[nb][e]);
                             }
@@ -398,23 +429,13 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
         __syncthreads();                                // every wave is done with this halo before the next one is written
     }
     if (stats) {
-        float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 * g.Cout;
+        float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 3 * g.Cout;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) cnt += __shfl_xor(cnt, o, 64);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = st1[nb][e], q = st2[nb][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {                  // over the 16 voxel lanes of a channel group
-                    a += __shfl_xor(a, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                if (li == 0) {
-                    const int c = co0 + nb * 16 + lg * 4 + e;
-                    sp[c] = a;
-                    sp[g.Cout + c] = q;
-                }
-            }
+            for (int e = 0; e < 4; ++e) stats_row_write(sp, g.Cout, co0 + nb * 16 + lg * 4 + e, st1[nb][e], st2[nb][e], shf[nb][e], cnt, li == 0);
     }
 }
 
@@ -528,17 +549,22 @@ __global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict
             __syncthreads();
         }
     }
-    float st1[NB][4], st2[NB][4];
+    float st1[NB][4], st2[NB][4], shf[NB][4];
+    float cnt = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) st1[nb][e] = st2[nb][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            st1[nb][e] = st2[nb][e] = 0.f;
+            shf[nb][e] = stats ? __shfl((float)(bf16)acc[0][0][nb][e], lane & 48, 64) : 0.f;      // the statistics' shift, see stats_row_write
+        }
 #pragma unroll
     for (int z = 0; z < TZT; ++z)
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z * 16 + li;
             if (gx < g.X && gy < g.Y && gz < g.Z) {
+                if (stats) cnt += 1.f;
                 bf16* yp = y + ((((int64_t)b * g.X + gx) * g.Y + gy) * g.Z + gz) * g.ldy + co0 + lg * 4;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -555,7 +581,7 @@ __global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict
                     if (stats) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float q = (float)o[e];
+                            const float q = (float)o[e] - shf[nb][e];
                             st1[nb][e] += q;
                             st2[nb][e] = fmaf(q, q, st2[nb][e]);
                         }
@@ -564,23 +590,13 @@ __global__ __launch_bounds__(CT) void conv3_fwd_mc_kernel(const bf16* __restrict
             }
         }
     if (stats) {                                                    // see conv_fwd_strip_kernel
-        float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 * g.Cout;
+        float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 3 * g.Cout;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) cnt += __shfl_xor(cnt, o, 64);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = st1[nb][e], q = st2[nb][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                if (li == 0) {
-                    const int c = co0 + nb * 16 + lg * 4 + e;
-                    sp[c] = a;
-                    sp[g.Cout + c] = q;
-                }
-            }
+            for (int e = 0; e < 4; ++e) stats_row_write(sp, g.Cout, co0 + nb * 16 + lg * 4 + e, st1[nb][e], st2[nb][e], shf[nb][e], cnt, li == 0);
     }
 }
 

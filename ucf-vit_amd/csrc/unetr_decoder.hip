@@ -356,47 +356,67 @@ __global__ __launch_bounds__(64) void incl_stats_final(const bf16* __restrict__ 
         rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
-// first stage of that fold when there are many partial rows (a full-resolution layer writes 32768 per batch element): workgroup (g, b)
-// adds the rows [g rpg, (g + 1) rpg) of [B][rows][C2] with coalesced reads (a thread owns a column, 256 / C2 rows in flight) -> [B][G][C2]
-__global__ __launch_bounds__(NT) void incl_stats_fold1(const float* __restrict__ part, float* __restrict__ out, int rows, int C2, int rpg) {
-    __shared__ float red[NT];
+// ---- fold of the convolution kernels' statistics epilogue: partial rows [B][rows][3][C] of (count, mean, M2) per channel (conv3d.hip:
+// stats_row_write) combined with the parallel-variance formula in double: n = na + nb, d = mb - ma, m = ma + d nb / n,
+// M2 = M2a + M2b + d^2 na nb / n.  Rows that stored nothing carry count 0 and drop out.
+struct Mom {
+    double n, m, m2;
+};
+__device__ __forceinline__ void mom_add(Mom& a, double nb, double mb, double m2b) {
+    if (nb <= 0.0) return;
+    const double n = a.n + nb, d = mb - a.m;
+    a.m += d * (nb / n);
+    a.m2 += m2b + d * d * (a.n * nb / n);
+    a.n = n;
+}
+// first stage when there are many partial rows (a full-resolution layer writes 32768 per batch element): workgroup (g, b) combines the rows
+// [g rpg, (g + 1) rpg) -> [B][G][3][C]; a thread owns a channel, NT / C rows in flight, the threads of a channel are combined in a fixed order
+__global__ __launch_bounds__(NT) void incl_stats_fold1(const float* __restrict__ part, float* __restrict__ out, int rows, int C, int rpg) {
+    __shared__ double red[3][NT];
     const int64_t b = blockIdx.y;
     const int g = blockIdx.x, G = gridDim.x;
     const int lo = g * rpg, hi = min(rows, lo + rpg);
-    for (int c0 = 0; c0 < C2; c0 += NT) {                       // C2 <= 256: one trip
-        const int w = min(C2 - c0, NT);                         // columns of this trip (a power of two: C2 = 2 C)
-        const int col = threadIdx.x % w, rl = threadIdx.x / w, rs = NT / w;
-        float s = 0.f;
-        for (int r = lo + rl; r < hi; r += rs) s += part[(b * rows + r) * C2 + c0 + col];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x < w) {
-            float t = 0.f;
-            for (int k = 0; k < rs; ++k) t += red[k * w + threadIdx.x];
-            out[(b * G + g) * C2 + c0 + threadIdx.x] = t;
-        }
-        __syncthreads();
+    const int w = min(C, NT);                                   // C <= 256, a power of two
+    const int col = threadIdx.x % w, rl = threadIdx.x / w, rs = NT / w;
+    Mom a = {0.0, 0.0, 0.0};
+    for (int r = lo + rl; r < hi; r += rs) {
+        const float* p = part + (b * rows + r) * 3 * C + col;
+        mom_add(a, (double)p[0], (double)p[C], (double)p[2 * C]);
+    }
+    red[0][threadIdx.x] = a.n;
+    red[1][threadIdx.x] = a.m;
+    red[2][threadIdx.x] = a.m2;
+    __syncthreads();
+    if (threadIdx.x < w) {
+        Mom t = {0.0, 0.0, 0.0};
+        for (int k = 0; k < rs; ++k) mom_add(t, red[0][k * w + threadIdx.x], red[1][k * w + threadIdx.x], red[2][k * w + threadIdx.x]);
+        float* o = out + (b * G + g) * 3 * C + threadIdx.x;
+        o[0] = (float)t.n;
+        o[C] = (float)t.m;
+        o[2 * C] = (float)t.m2;
     }
 }
-// the same fold for UNSHIFTED partial sums [B][rows][2][C] (sum, sum of squares) written by the convolution kernels' statistics epilogue
+// final stage: one wave per (b, channel) over the rows of [B][rows][3][C]
 __global__ __launch_bounds__(64) void incl_stats_fold(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int64_t S,
                                                       int C, int rows, float eps) {
     const int64_t b = blockIdx.x / C;
     const int c = blockIdx.x % C;
-    double s1 = 0.0, s2 = 0.0;
+    Mom a = {0.0, 0.0, 0.0};
     for (int r = threadIdx.x; r < rows; r += 64) {
-        s1 += part[(b * rows + r) * 2 * C + c];
-        s2 += part[(b * rows + r) * 2 * C + C + c];
+        const float* p = part + (b * rows + r) * 3 * C + c;
+        mom_add(a, (double)p[0], (double)p[C], (double)p[2 * C]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {                          // butterfly: every lane ends with the same combination order
+        const double nb = __shfl_xor(a.n, o, 64), mb = __shfl_xor(a.m, o, 64), m2b = __shfl_xor(a.m2, o, 64);
+        const bool lower = (threadIdx.x & o) == 0;              // combine (lower, upper) in that order on both sides
+        Mom lo = lower ? a : Mom{nb, mb, m2b};
+        if (lower) mom_add(lo, nb, mb, m2b); else mom_add(lo, a.n, a.m, a.m2);
+        a = lo;
     }
     if (threadIdx.x == 0) {
-        const double m = s1 / (double)S;
-        const double var = fmax(s2 / (double)S - m * m, 0.0);
-        mean[blockIdx.x] = (float)m;
+        const double var = a.n > 0.0 ? fmax(a.m2 / a.n, 0.0) : 0.0;             // a.n == S: every voxel of the batch element was stored once
+        mean[blockIdx.x] = (float)a.m;
         rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
@@ -967,17 +987,17 @@ extern "C" int ucfvit_instnorm_cl_bwd2(const void* dy, const void* y, const void
     return UCFVIT_OK;
 }
 
-// mean / rstd [B][C] from the partial sums [B][rows][2][C] of ucfvit_conv3d_fwd's statistics epilogue (S = voxels per batch element)
+// mean / rstd [B][C] from the partial rows [B][rows][3][C] (count, mean, M2) of ucfvit_conv3d_fwd's statistics epilogue (S = voxels per batch element)
 extern "C" int ucfvit_instnorm_cl_stats_fold(const float* partial, float* mean, float* rstd, int64_t B, int64_t S, int64_t C, int64_t rows, float eps,
-                                             void* workspace, void* stream) {      // workspace: B * 256 * 2 C floats (may be NULL: single stage)
+                                             void* workspace, void* stream) {      // workspace: B * 256 * 3 C floats (may be NULL: single stage)
     UCF_CHECK_ARG(partial && mean && rstd && B > 0 && S > 0 && C > 0 && rows > 0 && B * C < (1ll << 31) && rows < (1ll << 31),
                   "ucfvit_instnorm_cl_stats_fold: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (rows > 512 && workspace && (C & (C - 1)) == 0) {
+    if (rows > 512 && workspace && (C & (C - 1)) == 0 && C <= NT) {
         // two stages: 128..256 row groups per batch element first (coalesced), then the per-channel fold over the groups
         const int G = (int)((rows + 255) / 256) > 256 ? 256 : (int)((rows + 255) / 256);
         const int rpg = (int)((rows + G - 1) / G);
-        hipLaunchKernelGGL(incl_stats_fold1, dim3(G, (unsigned)B), dim3(NT), 0, s, partial, (float*)workspace, (int)rows, (int)(2 * C), rpg);
+        hipLaunchKernelGGL(incl_stats_fold1, dim3(G, (unsigned)B), dim3(NT), 0, s, partial, (float*)workspace, (int)rows, (int)C, rpg);
         hipLaunchKernelGGL(incl_stats_fold, dim3((unsigned)(B * C)), dim3(64), 0, s, (const float*)workspace, mean, rstd, S, (int)C, G, eps);
     } else {
         hipLaunchKernelGGL(incl_stats_fold, dim3((unsigned)(B * C)), dim3(64), 0, s, partial, mean, rstd, S, (int)C, (int)rows, eps);
