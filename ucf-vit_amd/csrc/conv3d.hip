@@ -195,9 +195,15 @@ __global__ __launch_bounds__(CT) void conv_fwd_kernel(const bf16* __restrict__ x
 // walks the whole z extent of its (x, y) tile column.  The weight slab is staged once; the halo of tile z + 1 is fetched into registers while
 // tile z is multiplied out of LDS, so the global-load latency (the dominant cost of the one-tile-per-workgroup kernel at these sizes:
 // ~60..100 MFMAs per wave per tile) is hidden behind the MFMA work.
-template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
+// FAST (picked by the launcher when the output rows are 4-channel aligned and every tensor of a batch element is below 4 GB): the halo loads,
+// the loads of the values to accumulate onto and the output stores are range-checked RAW BUFFER operations whose offset is pushed out of range
+// for voxels outside the volume — no branch around any memory operation, so hipcc counts them exactly (vmcnt(n) instead of vmcnt(0) at the
+// halo store) and DEPTH = 2 halo tiles can be in flight per workgroup instead of one (the kernel waits on global memory, see
+// profiles/r03_n_decoder_strip_kernel.txt).
+template <int CPC, int NB, int TX, int TY, int KS, typename OutT, bool FAST = false, int DEPTH = 1>
 __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                             OutT* __restrict__ y, ConvGeo g, float* __restrict__ stats) {
+    static_assert(FAST || DEPTH == 1, "two tiles in flight need the branch-free memory operations");
     typedef CG<CPC, KS> G;
     constexpr int PAD = G::PAD, HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = 16 + 2 * PAD;
     constexpr int HALO_BYTES = HX * HY * HZ * G::VS;
@@ -257,19 +263,35 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
         hzz[i] = ((hz - PAD) & 0xffff) | (piece << 16);
     }
     const bf16* xb = x + (int64_t)b * g.X * g.Y * g.Z * g.Cin;
-    u32x4 pre[NPT];
-    auto fetch = [&](int z0) {
+    OutT* yb = y + (int64_t)b * g.X * g.Y * g.Z * g.ldy;
+    constexpr unsigned OOB = 0xFFFFFFF0u;              // beyond every resource below: loads return 0, stores are dropped
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(xb), 0, FAST ? (int)((unsigned)g.X * g.Y * g.Z * g.Cin * 2u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(yb, 0, FAST ? (int)((unsigned)g.X * g.Y * g.Z * g.ldy * (unsigned)sizeof(OutT)) : 0, 0x00020000);
+    u32x4 pre[DEPTH][NPT];
+    auto fetch = [&](int z0, u32x4 (&dst)[NPT]) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int gz = z0 + (int)(short)(hzz[i] & 0xffff), piece = hzz[i] >> 16;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (hxy[i] >= 0 && (unsigned)gz < (unsigned)g.Z)
-                v = *reinterpret_cast<const u32x4*>(xb + ((int64_t)hxy[i] * g.Z + gz) * g.Cin + piece * 8);
-            pre[i] = v;
+            if constexpr (FAST) {
+                const bool ok = hxy[i] >= 0 && (unsigned)gz < (unsigned)g.Z;
+                const unsigned off = (((unsigned)hxy[i] * (unsigned)g.Z + (unsigned)gz) * (unsigned)g.Cin + (unsigned)piece * 8u) * 2u;
+                dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? off : OOB), 0, 0);
+            } else {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (hxy[i] >= 0 && (unsigned)gz < (unsigned)g.Z)
+                    v = *reinterpret_cast<const u32x4*>(xb + ((int64_t)hxy[i] * g.Z + gz) * g.Cin + piece * 8);
+                dst[i] = v;
+            }
         }
     };
-    fetch(0);
+    fetch(0, pre[0]);
+    if constexpr (DEPTH == 2) fetch(16, pre[1]);       // (beyond the last tile: out of range, no traffic)
     const bool vec_ok = (g.ldy & 3) == 0;
+    float bv[NB][4];                                    // this lane's bias values (FAST: fetched once, no load under a branch in the tile loop)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[nb][e] = (FAST && bias) ? bias[co0 + nb * 16 + lg * 4 + e] : 0.f;
     // stats (optional): per-channel sum and sum of squares of the ROUNDED outputs of this column, per wave — the instance-norm statistics of the
     // layer's output without a pass over it ([column * 4 + wave][2][Cout] partials, folded by ucfvit_instnorm_cl_stats_fold)
     float st1[NB][4], st2[NB][4], shf[NB][4];
@@ -278,15 +300,35 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) st1[nb][e] = st2[nb][e] = shf[nb][e] = 0.f;
-    for (int iz = 0; iz < g.tz; ++iz) {
+    // one z tile: its halo (in `buf`) into LDS, the registers of `buf` re-used for the tile DEPTH ahead, MFMAs, epilogue
+    auto tile = [&](int iz, u32x4 (&buf)[NPT]) __attribute__((always_inline)) {
         const int z0 = iz * 16;
 #pragma unroll
         for (int i = 0; i < NPT; ++i)
-            if (tid + i * CT < NP) *reinterpret_cast<u32x4*>(halo + hoff[i]) = pre[i];
+            if (tid + i * CT < NP) *reinterpret_cast<u32x4*>(halo + hoff[i]) = buf[i];
         __syncthreads();
-        if (iz + 1 < g.tz) fetch(z0 + 16);              // in flight during the MFMA work below
         Vec4<OutT> prev[RPW][NB];                       // accumulate: the values to add to, fetched now and used in the epilogue
-        if (g.accumulate && vec_ok) {
+        if constexpr (!FAST) {
+            if (iz + 1 < g.tz) fetch(z0 + 16, buf);     // in flight during the MFMA work below
+        }
+        if constexpr (FAST) {
+            // (requested BEFORE the halo tiles: the epilogue's wait for them must not include the younger halo loads — vmcnt retires in order)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
+                const bool valid = g.accumulate && gx < g.X && gy < g.Y && gz < g.Z;
+                const unsigned vox = ((unsigned)gx * (unsigned)g.Y + (unsigned)gy) * (unsigned)g.Z + (unsigned)gz;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c = co0 + nb * 16 + lg * 4;
+                    const unsigned off = (vox * (unsigned)g.ldy + (unsigned)c) * (unsigned)sizeof(OutT);
+                    const int o = (int)((valid && c + 4 <= g.cout_store) ? off : OOB);
+                    if constexpr (sizeof(OutT) == 2) prev[r][nb] = __builtin_bit_cast(Vec4<OutT>, __builtin_amdgcn_raw_buffer_load_b64(rY, o, 0, 0));
+                    else prev[r][nb] = __builtin_bit_cast(Vec4<OutT>, __builtin_amdgcn_raw_buffer_load_b128(rY, o, 0, 0));
+                }
+            }
+            fetch(z0 + 16 * DEPTH, buf);                // DEPTH tiles ahead, into the registers the halo store above has just freed
+        } else if (g.accumulate && vec_ok) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
@@ -385,10 +427,38 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v0 = acc[0][nb][e] + (bias ? bias[co0 + nb * 16 + lg * 4 + e] : 0.f);
+                    const float v0 = acc[0][nb][e] + (FAST ? bv[nb][e] : (bias ? bias[co0 + nb * 16 + lg * 4 + e] : 0.f));
                     shf[nb][e] = __shfl(to_f32<OutT>(from_f32<OutT>(v0)), lane & 48, 64);
                 }
         }
+        if constexpr (FAST) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
+                const bool valid = gx < g.X && gy < g.Y && gz < g.Z;
+                const unsigned vox = ((unsigned)gx * (unsigned)g.Y + (unsigned)gy) * (unsigned)g.Z + (unsigned)gz;
+                if (stats && valid) cnt += 1.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c = co0 + nb * 16 + lg * 4;
+                    Vec4<OutT> o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.set(e, acc[r][nb][e] + bv[nb][e] + prev[r][nb].get(e));      // prev: zeros unless accumulating
+                    const unsigned off = (vox * (unsigned)g.ldy + (unsigned)c) * (unsigned)sizeof(OutT);
+                    const int ob = (int)((valid && c + 4 <= g.cout_store) ? off : OOB);
+                    if constexpr (sizeof(OutT) == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rY, ob, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rY, ob, 0, 0);
+                    if (stats && valid) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float q = o.get(e) - shf[nb][e];
+                            st1[nb][e] += q;
+                            st2[nb][e] = fmaf(q, q, st2[nb][e]);
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int row = wave * RPW + r, gx = x0 + row / TY, gy = y0 + row % TY, gz = z0 + li;
@@ -426,7 +496,18 @@ __global__ __launch_bounds__(CT) void conv_fwd_strip_kernel(const bf16* __restri
                 }
             }
         }
+        }
         __syncthreads();                                // every wave is done with this halo before the next one is written
+    };
+    if constexpr (DEPTH == 2) {
+        // two tiles per trip, each with its own register set (no copy between them: a copy would wait for the younger tile's loads); with an
+        // odd tile count the last trip's second tile lies beyond the volume: its loads and stores are out of range, its arithmetic is wasted
+        for (int iz = 0; iz < g.tz; iz += 2) {
+            tile(iz, pre[0]);
+            tile(iz + 1, pre[1]);
+        }
+    } else {
+        for (int iz = 0; iz < g.tz; ++iz) tile(iz, pre[0]);
     }
     if (stats) {
         float* sp = stats + ((int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 3 * g.Cout;
@@ -812,27 +893,41 @@ int launch_fwd(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGe
     return UCFVIT_OK;
 }
 
+static int strip_mode();
+
+template <int CPC, int NB, int TX, int TY, int KS, typename OutT, bool FAST, int DEPTH>
+int launch_fwd_strip_v(const bf16* x, const bf16* wp, const float* bias, OutT* y, const ConvGeo& g, float* stats, int64_t cols, hipStream_t s) {
+    typedef CG<CPC, KS> G;
+    constexpr int WSLOTS = (KS == 3 && CPC == 16) ? 15 : G::NTS;            // the dy-free step arrangement of conv_fwd_strip_kernel (SHARE)
+    constexpr int SMEM = (TX + 2 * G::PAD) * (TY + 2 * G::PAD) * (16 + 2 * G::PAD) * G::VS + WSLOTS * 16 * NB * 64;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT, FAST, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT, FAST, DEPTH>), dim3((unsigned)cols, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp,
+                       bias, y, g, stats);
+    UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
+    return UCFVIT_OK;
+}
+
 template <int CPC, int NB, int TX, int TY, int KS, typename OutT>
 int launch_fwd_strip(const bf16* x, const bf16* wp, const float* bias, OutT* y, ConvGeo g, float* stats, hipStream_t s) {
-    typedef CG<CPC, KS> G;
     g.tx = (g.X + TX - 1) / TX;
     g.ty = (g.Y + TY - 1) / TY;
     g.tz = (g.Z + 15) / 16;
     const int64_t cols = (int64_t)g.B * g.tx * g.ty;
     UCF_CHECK_ARG(cols < (1ll << 31) && g.Cout / (16 * NB) < 65536, "ucfvit_conv3d_fwd: grid too large");
     g.tiles = (int)cols;
-    constexpr int WSLOTS = (KS == 3 && CPC == 16) ? 15 : G::NTS;            // the dy-free step arrangement of conv_fwd_strip_kernel (SHARE)
-    constexpr int SMEM = (TX + 2 * G::PAD) * (TY + 2 * G::PAD) * (16 + 2 * G::PAD) * G::VS + WSLOTS * 16 * NB * 64;
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_done = true;
+    // the branch-free form (see conv_fwd_strip_kernel): 4-channel aligned output rows, a batch element's input and output below 4 GB
+    const int64_t vox = (int64_t)g.X * g.Y * g.Z, lim = (1ll << 32) - 64;
+    const bool fast = (g.ldy & 3) == 0 && (g.cout_store & 3) == 0 && vox * g.Cin * 2 < lim && vox * g.ldy * (int64_t)sizeof(OutT) < lim && strip_mode() != 3;
+    if (fast) {
+        if constexpr (CPC <= 16) return launch_fwd_strip_v<CPC, NB, TX, TY, KS, OutT, true, 2>(x, wp, bias, y, g, stats, cols, s);
+        else return launch_fwd_strip_v<CPC, NB, TX, TY, KS, OutT, true, 1>(x, wp, bias, y, g, stats, cols, s);
     }
-    hipLaunchKernelGGL((conv_fwd_strip_kernel<CPC, NB, TX, TY, KS, OutT>), dim3((unsigned)cols, g.Cout / (16 * NB)), dim3(CT), SMEM, s, x, wp, bias,
-                       y, g, stats);
-    UCF_LAUNCH_CHECK("ucfvit_conv3d_fwd");
-    return UCFVIT_OK;
+    return launch_fwd_strip_v<CPC, NB, TX, TY, KS, OutT, false, 1>(x, wp, bias, y, g, stats, cols, s);
 }
 
 template <int TZT>
@@ -859,7 +954,7 @@ int launch_fwd_mc(const bf16* x, const bf16* wp, bf16* y, ConvGeo g, float* stat
 static int strip_mode() {
     static const int flag = [] {
         const char* e = getenv("UCFVIT_CONV_STRIP");
-        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+        return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;      // 3 (test hook): column kernels with the branching memory operations
     }();
     return flag;
 }
